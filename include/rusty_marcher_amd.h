@@ -1,0 +1,241 @@
+/*
+ * rusty_marcher_amd.h -- C ABI of the MI355X render backend.
+ *
+ * Drop-in boundary for ONE hot path of blefaudeux/rusty-marcher: the call
+ *     raymarcher.render(&mut self.fb, &self.scene)      (engine/src/main.rs:331-333)
+ * i.e. Renderer::render (renderer.rs:36-126) and everything below it
+ * (cast_ray, the Shape::intersect implementations, optics, lighting).
+ * The reference has no FFI of its own; these are the entry points a Rust
+ * `extern "C"` block for that path binds (see INTEGRATION.md for the shim).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; every struct below is `#[repr(C)]`-able.
+ *   - all arithmetic types are IEEE-754 binary64 (geometry.rs:4-8).
+ *   - every call returns rm_status; nothing unwinds across the boundary.  The
+ *     reference's failure mode is a panic, so the Rust shim turns a non-zero
+ *     status into `panic!("{}", rm_last_error(..))`.
+ *   - one caller at a time per rm_ctx / rm_scene (the reference calls render on
+ *     the GTK main thread and blocks until the frame is complete).
+ *   - the render entry points FAIL (RM_ERR_NO_DEVICE / RM_ERR_HIP) when no
+ *     gfx950 device or kernel image is available; there is no CPU fallback.
+ */
+#ifndef RUSTY_MARCHER_AMD_H
+#define RUSTY_MARCHER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_ABI_VERSION 1u
+
+typedef enum rm_status {
+    RM_OK = 0,
+    RM_ERR_INVALID_ARG = 1,
+    RM_ERR_DIMENSIONS = 2,   /* width % 32 != 0: the reference's scatter indexes out of
+                                bounds and panics (renderer.rs:92-108) */
+    RM_ERR_NO_DEVICE = 3,
+    RM_ERR_HIP = 4,
+    RM_ERR_NO_SCENE = 5,     /* rm_render before rm_scene_upload */
+    RM_ERR_SCENE_LIMIT = 6,  /* scene exceeds a documented device limit */
+    RM_ERR_IO = 7,           /* file missing (obj.rs:53-56 returns None; a missing mtllib
+                                panics "WOOPS", obj.rs:64) */
+    RM_ERR_PARSE = 8,
+    RM_ERR_DEPTH = 9         /* max_depth outside [0, RM_MAX_DEPTH] */
+} rm_status;
+
+/* Recursion cap accepted by rm_render.  The reference hard-codes 3
+ * (renderer.rs:262) and counts in a u8. */
+#define RM_MAX_DEPTH 32u
+/* The reference's patch edge (renderer.rs:47); the only value accepted. */
+#define RM_PATCH_SIZE 32u
+
+/* geometry.rs:4-8 `Vec3f` */
+typedef struct rm_vec3 { double x, y, z; } rm_vec3;
+
+/* shapes.rs:20-32 `Reflectance` (bool widened to a 32-bit int + padding) */
+typedef struct rm_reflectance {
+    double  diffusion;
+    rm_vec3 diffuse_color;
+    double  specular;
+    double  specular_exponent;
+    int32_t is_glass_like;
+    int32_t _pad;
+    double  reflection;
+    double  refractive_index;
+} rm_reflectance;
+
+/* lights.rs:4-8 `Light`; colour already L-inf normalised (lights.rs:10-16) */
+typedef struct rm_light { rm_vec3 position, color; double intensity; } rm_light;
+
+/* sphere.rs:6-11 `Sphere` (bounding box dropped: never consulted, shapes.rs:34-86) */
+typedef struct rm_sphere { rm_vec3 center; double radius_square; rm_reflectance reflectance; } rm_sphere;
+
+/* polygon.rs:6-12 `ConvexPolygon`; vertices live in rm_scene_desc.polygon_vertices */
+typedef struct rm_polygon {
+    uint32_t first_vertex, n_vertices;
+    rm_vec3  plane_normal, plane_point;
+    rm_reflectance reflectance;
+} rm_polygon;
+
+/* triangle.rs:6-10 `Triangle` + its entry of Obj.reflectances (obj.rs:16) */
+typedef struct rm_triangle {
+    rm_vec3 vertices[3];
+    rm_vec3 normal, center;
+    rm_reflectance reflectance;
+} rm_triangle;
+
+typedef enum rm_shape_kind { RM_SHAPE_SPHERE = 0, RM_SHAPE_POLYGON = 1, RM_SHAPE_MESH = 2 } rm_shape_kind;
+
+/* One element of Scene.shapes: Vec<Box<dyn Shape + Sync>> (scene.rs:11), in list
+ * order (the order decides ties, shapes.rs:130 and obj.rs:198).
+ * SPHERE/POLYGON: `first` indexes spheres[]/polygons[], count == 1.
+ * MESH (an obj.rs `Obj`): triangles[first .. first+count). */
+typedef struct rm_shape_ref { uint32_t kind, first, count, _pad; } rm_shape_ref;
+
+/* Flat, pointer-and-size view of scene.rs:9-13 `Scene`. */
+typedef struct rm_scene_desc {
+    const rm_shape_ref *shapes;            uint32_t n_shapes;
+    const rm_sphere    *spheres;           uint32_t n_spheres;
+    const rm_polygon   *polygons;          uint32_t n_polygons;
+    const rm_vec3      *polygon_vertices;  uint32_t n_polygon_vertices;
+    const rm_triangle  *triangles;         uint32_t n_triangles;
+    const rm_light     *lights;            uint32_t n_lights;
+    rm_vec3 camera;
+} rm_scene_desc;
+
+/* renderer.rs:17-23 `Renderer` + the frame geometry render() reads from the
+ * FrameBuffer (renderer.rs:49-55) + the constants it hard-codes. */
+typedef struct rm_params {
+    /* Renderer, as create_renderer(fov, height, width) fills it (renderer.rs:25-33) */
+    double fov, half_fov, height, width, ratio;
+    /* FrameBuffer.width / .height (framebuffer.rs:6-10) */
+    uint32_t frame_width, frame_height;
+    /* renderer.rs:262 (reference: 3) */
+    uint32_t max_depth;
+    /* renderer.rs:47 (must be RM_PATCH_SIZE) */
+    uint32_t patch_size;
+    /* renderer.rs:40-44 (reference: 0.1, 0.1, 0.1) */
+    rm_vec3 background;
+    /* Row band owned by this caller, in patch rows: [begin, end).  end == 0 means
+     * "all frame_height/32 patch rows".  Pixels outside the band are untouched. */
+    uint32_t patch_row_begin, patch_row_end;
+    uint32_t flags;        /* RM_FLAG_* */
+    uint32_t _pad;
+} rm_params;
+
+#define RM_FLAG_NONE 0u
+
+typedef struct rm_timing {
+    double kernel_ms;   /* HIP-event time of the render kernel on its stream */
+    double d2h_ms;      /* device -> host copy (0 when host_rgb == NULL) */
+    double total_ms;    /* host wall time of the call */
+} rm_timing;
+
+typedef struct rm_scene rm_scene;   /* host-side scene builder (opaque) */
+typedef struct rm_ctx rm_ctx;       /* one GPU: stream, device scene, framebuffer (opaque) */
+
+/* ---------------------------------------------------------------------- */
+/* Host side: scene construction.  Replaces the constructors the reference  */
+/* runs before render(): nothing here touches the GPU.                      */
+/* ---------------------------------------------------------------------- */
+
+/* shapes.rs:49-61 Reflectance::create_default */
+void rm_reflectance_default(rm_reflectance *out);
+
+/* renderer.rs:25-33 create_renderer(fov, height, width) -- note the argument order.
+ * Fills fov/half_fov/height/width/ratio, sets frame_* from (width, height) truncated,
+ * max_depth = 3, patch_size = 32, background = 0.1, full band, flags = 0. */
+void rm_create_renderer(double fov, double height, double width, rm_params *out);
+
+rm_status rm_scene_new(rm_scene **out);                                   /* scene.rs:16-23 */
+void      rm_scene_free(rm_scene *scene);
+rm_status rm_scene_create_default(rm_scene **out);                        /* scene.rs:28-211 */
+/* sphere.rs:13-24 */
+rm_status rm_scene_add_sphere(rm_scene *scene, rm_vec3 center, double radius, const rm_reflectance *r);
+/* polygon.rs:16-42; n_vertices < 3 -> RM_ERR_INVALID_ARG (reference asserts) */
+rm_status rm_scene_add_polygon(rm_scene *scene, const rm_vec3 *vertices, uint32_t n_vertices,
+                               const rm_reflectance *r);
+/* One obj.rs `Obj`: n triangles as 9 doubles each; per-triangle colour ramp of
+ * obj.rs:125-138; then Obj::offset(offset) (obj.rs:24-29, triangle.rs:19-24). */
+rm_status rm_scene_add_mesh(rm_scene *scene, const double *tri_xyz, uint32_t n_triangles, rm_vec3 offset);
+/* lights.rs:10-16 */
+rm_status rm_scene_add_light(rm_scene *scene, rm_vec3 position, rm_vec3 color, double intensity);
+/* ConvexPolygon::offset (polygon.rs:44-49) / Obj::offset (obj.rs:24-29): moves shape
+ * `shape_index` of the list (plane point or triangle centres, and vertices; normals
+ * are kept).  Spheres have no offset method in the reference -> RM_ERR_INVALID_ARG. */
+rm_status rm_scene_offset_shape(rm_scene *scene, uint32_t shape_index, rm_vec3 offset);
+rm_status rm_scene_set_camera(rm_scene *scene, rm_vec3 camera);
+rm_status rm_scene_offset_camera(rm_scene *scene, rm_vec3 offset);       /* scene.rs:25-27 */
+/* obj.rs:44-151 obj::load: appends one MESH shape per model of the file, each
+ * moved by `offset`; *n_models_out (optional) receives the model count. */
+rm_status rm_scene_load_obj(rm_scene *scene, const char *path, rm_vec3 offset, uint32_t *n_models_out);
+/* main.rs:261-327 Win::open_obj: new scene = load(path) offset by (0,0,-500) + the
+ * two hard-coded lights. */
+rm_status rm_scene_open_obj(const char *path, rm_scene **out);
+/* Flat view; pointers stay valid until the scene is next modified or freed. */
+rm_status rm_scene_get_desc(const rm_scene *scene, rm_scene_desc *out);
+
+/* renderer.rs:111-121: "Scene rendered in {} ms ({} fps, {:.2} MP/s)".
+ * Returns the length written (snprintf semantics). */
+int rm_format_status(char *buf, size_t buflen, uint64_t ms, uint32_t frame_width, uint32_t frame_height);
+
+/* ---------------------------------------------------------------------- */
+/* Device side: the render path.                                            */
+/* ---------------------------------------------------------------------- */
+
+/* Binds HIP device `device_ordinal` (one process per GPU), creates its stream. */
+rm_status rm_init(int device_ordinal, rm_ctx **out);
+void      rm_destroy(rm_ctx *ctx);
+/* Last error text of `ctx`; ctx == NULL -> last error of a host-side call or of a
+ * failed rm_init on this thread.  Never NULL. */
+const char *rm_last_error(const rm_ctx *ctx);
+
+/* Copies the scene into device memory (arrays are copied; caller keeps ownership). */
+rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *desc);
+/* scene.rs:25-27 without re-upload: replaces the camera of the uploaded scene. */
+rm_status rm_camera_update(rm_ctx *ctx, rm_vec3 camera);
+
+/*
+ * Renderer::render (renderer.rs:36-126) for the patch rows of params' band.
+ * host_rgb: [frame_height][frame_width][3] doubles row-major (framebuffer.rs:12-22
+ * flattened), caller-allocated; only the band's rows are written, so rows
+ * >= frame_height - frame_height%32 keep their previous contents exactly as in the
+ * reference.  NULL leaves the result in the context's device framebuffer.
+ * Blocks until host_rgb is filled (or, for NULL, until the kernel has finished).
+ */
+rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing);
+
+/*
+ * Same kernel, asynchronous, into a caller-owned DEVICE buffer with the same
+ * [frame_height][frame_width][3] layout, enqueued on `hip_stream` (a hipStream_t;
+ * NULL = the context's stream).  Returns once enqueued.
+ */
+rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream);
+
+/* Device framebuffer of the last rm_render(.., NULL, ..) and its size in bytes. */
+rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes);
+
+/*
+ * framebuffer.rs:58-77 normalize + :40-55 to_vec/:80-82 quantize, on the device.
+ * device_rgb: [h][w][3] doubles (NULL = the context's framebuffer).  The global max
+ * is taken over ALL h*w pixels (unrendered rows included, as the reference does).
+ *   normalize != 0 : scales device_rgb in place by 1/max (if max > 0), as
+ *                    FrameBuffer::normalize does before write_ppm (main.rs:355-356)
+ *   host_rgb8      : optional [h][w][3] bytes, receives to_vec() of the result
+ *   max_out        : optional, receives the global max found (0 when !normalize)
+ */
+rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t frame_width, uint32_t frame_height,
+                         int normalize, uint8_t *host_rgb8, double *max_out);
+
+/* Library / device introspection for harnesses. */
+uint32_t    rm_abi_version(void);
+const char *rm_build_info(void);
+rm_status   rm_device_info(rm_ctx *ctx, char *name_buf, size_t buflen, int *n_cus, size_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTY_MARCHER_AMD_H */

@@ -178,7 +178,9 @@ class OracleScene:
 
     @property
     def c(self):
-        return self.ptr.contents
+        c = self.ptr.contents
+        c._owner = self     # the struct borrows this scene's arrays
+        return c
 
 
 def reflectance(diffusion=1., diffuse_color=(1., 1., 1.), specular=1., specular_exponent=30.,

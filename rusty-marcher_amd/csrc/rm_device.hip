@@ -1,0 +1,648 @@
+// rm_device.hip -- device half of the C ABI: context, scene upload, the render
+// kernel and the framebuffer post-process kernels.  gfx950 (MI355X) only.
+//
+// Replaces Renderer::render's Rayon patch loop (renderer.rs:63-89), the serial
+// scatter (renderer.rs:92-108) and cast_ray's recursion (renderer.rs:254-309).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rm_internal.h"
+#include "rm_trace.hpp"
+
+using namespace rmdev;
+
+#ifndef RM_BUILD_FLAVOR
+#define RM_BUILD_FLAVOR "strict-fp64"
+#endif
+
+// ---------------------------------------------------------------------------
+// Render kernel
+//
+// One 256-thread workgroup renders one 32x32 patch -- the reference's unit of
+// parallel work (renderer.rs:47,63-89).  The patch is cut into sixteen 8x8
+// tiles; wave w renders tiles w, w+4, w+8, w+12, one lane per pixel, so the 64
+// rays of a wave stay spatially coherent (same primitives hit, same branches).
+// cast_ray's recursion becomes a per-lane depth-first walk of the ray tree with
+// an explicit stack: radiance is linear in the children (renderer.rs:219,249),
+// so each ray carries the product of the reflection factors above it.
+// ---------------------------------------------------------------------------
+
+struct KernelArgs {
+    rm_dev_header H;
+    double half_fov, height, width, ratio;   // Renderer (renderer.rs:17-23)
+    double cam_x, cam_y, cam_z;              // Scene.camera
+    double bg_x, bg_y, bg_z;                 // renderer.rs:40-44
+    uint32_t frame_width;                    // FrameBuffer.width
+    uint32_t patch_row_begin;                // first patch row of the band
+    uint32_t max_depth;                      // renderer.rs:262
+    uint32_t _pad;
+};
+
+struct StackEntry {
+    double ox, oy, oz, dx, dy, dz, w;
+    uint32_t depth, _pad;
+};
+
+extern __shared__ double rm_lds[];
+
+template <int STACK>
+__global__ __launch_bounds__(256) void rm_render_kernel(const double *__restrict__ scene_blob, KernelArgs a,
+                                                         double *__restrict__ frame) {
+    // ---- stage the scene in LDS (every lane then reads it as broadcasts) ----
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(scene_blob);
+        double2 *dst = reinterpret_cast<double2 *>(rm_lds);
+        const uint32_t n2 = a.H.total_words / 2;
+        for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = src[i];
+    }
+    // per-wave 8x8x3 transpose slab for the output stores, behind the scene
+    double *slab = rm_lds + a.H.total_words + (threadIdx.x >> 6) * (64 * 3);
+    __syncthreads();
+
+    SceneView sc;
+    sc.S = rm_lds;
+    sc.H = a.H;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t px0 = blockIdx.x * 32u;                        // renderer.rs:69
+    const uint32_t py0 = (a.patch_row_begin + blockIdx.y) * 32u;  // renderer.rs:70
+    const V3 cam = mk(a.cam_x, a.cam_y, a.cam_z);
+    const V3 bg = mk(a.bg_x, a.bg_y, a.bg_z);
+
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t tile = k * 4u + wave;
+        const uint32_t tx0 = px0 + (tile & 3u) * 8u;
+        const uint32_t ty0 = py0 + (tile >> 2) * 8u;
+        const uint32_t x = tx0 + (lane & 7u);
+        const uint32_t y = ty0 + (lane >> 3);
+
+        // backproject, renderer.rs:128-135 (no pixel-centre offset)
+        V3 dir = normalized(mk(2. * ((double)x / a.width - 0.5) * a.half_fov * a.ratio,
+                               -2. * ((double)y / a.height - 0.5) * a.half_fov, -1.));
+        V3 orig = cam;
+        double weight = 1.;
+        uint32_t depth = 1;                                       // renderer.rs:83
+        V3 acc = mk(0., 0., 0.);
+
+        StackEntry stack[STACK];
+        int sp = 0;
+
+        for (;;) {
+            Hit h;
+            bool descend = false;
+            if (closest_hit(sc, orig, dir, h)) {
+                const Surface s = surface_at(sc, orig, dir, h);
+                // renderer.rs:272-275: background + direct lighting
+                const V3 L = bg + shade_direct(sc, orig, s);
+                acc = acc + scaled(L, weight);
+                if (s.mat[8] != 0.) {                             // is_glass_like, renderer.rs:277
+                    const double reflection = s.mat[6], ri = s.mat[7];
+                    const V3 incident = dir;
+                    const double w_here = weight;
+                    const uint32_t child_depth = depth + 1u;
+                    // a child beyond the cap returns the background (renderer.rs:262-264)
+                    const bool child_capped = child_depth > a.max_depth;
+                    V3 co, cd;
+                    if (reflect_child(incident, s, ri, co, cd)) { // renderer.rs:195-222
+                        const double cw = w_here * reflection;
+                        if (child_capped) {
+                            acc = acc + scaled(bg, cw);
+                        } else {                                  // pending sibling: at most one per level
+                            StackEntry &e = stack[sp++];
+                            e.ox = co.x; e.oy = co.y; e.oz = co.z;
+                            e.dx = cd.x; e.dy = cd.y; e.dz = cd.z;
+                            e.w = cw; e.depth = child_depth;
+                        }
+                    }
+                    if (refract_child(incident, s, ri, co, cd)) { // renderer.rs:225-252
+                        const double cw = w_here * (1. - reflection);
+                        if (child_capped) {
+                            acc = acc + scaled(bg, cw);
+                        } else {                                  // walk into this child directly
+                            orig = co; dir = cd; weight = cw; depth = child_depth;
+                            descend = true;
+                        }
+                    }
+                }
+            } else if (depth > 1u) {
+                acc = acc + scaled(bg, weight);                   // renderer.rs:302-303
+            }                                                     // primary miss: zero, :305
+            if (descend) continue;
+            if (sp == 0) break;
+            const StackEntry &e = stack[--sp];
+            orig = mk(e.ox, e.oy, e.oz);
+            dir = mk(e.dx, e.dy, e.dz);
+            weight = e.w;
+            depth = e.depth;
+        }
+
+        // ---- store the 8x8 tile: transpose through LDS so that each of the 8 rows
+        // leaves as 192 contiguous bytes in 16-byte pieces (frame.buffer[y][x], :103)
+        slab[lane * 3 + 0] = acc.x;
+        slab[lane * 3 + 1] = acc.y;
+        slab[lane * 3 + 2] = acc.z;
+        __builtin_amdgcn_wave_barrier();
+        const double2 *slab2 = reinterpret_cast<const double2 *>(slab);
+        for (uint32_t q = lane; q < 96u; q += 64u) {
+            const uint32_t row = q / 12u, piece = q % 12u;       // 12 x 16 B per 8-pixel row
+            double2 *dst = reinterpret_cast<double2 *>(frame + ((size_t)(ty0 + row) * a.frame_width + tx0) * 3u);
+            dst[piece] = slab2[row * 12u + piece];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// With max_depth == 0 the primary ray itself is capped: every pixel is the
+// background (renderer.rs:262-264 with n_recursion = 1 > 0).
+__global__ void rm_fill_band_kernel(double *frame, size_t first_px, size_t n_px, double r, double g, double b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_px) {
+        double *p = frame + (first_px + i) * 3;
+        p[0] = r; p[1] = g; p[2] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Post-process kernels: framebuffer.rs:58-77 (normalize) and :40-55,:80-82
+// (to_vec / quantize).
+// ---------------------------------------------------------------------------
+
+// Global max over all channel values, starting from 0 like the reference's
+// `max = Vec3f::zero()`; f64::max ignores NaN, as fmax does.  Values are >= 0
+// after max(0, .), so their bit patterns order like unsigned integers.
+__global__ __launch_bounds__(256) void rm_max_kernel(const double *__restrict__ v, size_t n, unsigned long long *out_bits) {
+    double m = 0.;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = __builtin_fmax(m, v[i]);
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmax(m, __shfl_down(m, off));
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = __builtin_fmax(__builtin_fmax(part[0], part[1]), __builtin_fmax(part[2], part[3]));
+        atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// Optional in-place scale by 1/max (framebuffer.rs:69-76) and optional u8 output
+// `(255. * f.max(0.).min(1.)) as u8` (truncating, NaN -> 0).
+__global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restrict__ v, size_t n, const unsigned long long *max_bits,
+                                                               int do_scale, uint8_t *__restrict__ out8) {
+    double s = 1.;
+    bool scale = false;
+    if (do_scale) {
+        const double max_val = __longlong_as_double((long long)*max_bits);
+        if (max_val > 0.) { s = 1. / max_val; scale = true; }
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double f = v[i];
+        if (scale) { f = f * s; v[i] = f; }
+        if (out8) {
+            const double c = 255. * __builtin_fmin(__builtin_fmax(f, 0.), 1.);
+            out8[i] = (uint8_t)c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------
+
+struct rm_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string error;
+    hipDeviceProp_t prop{};
+
+    // uploaded scene
+    bool have_scene = false;
+    rm_dev_header H{};
+    double *d_scene = nullptr;
+    size_t d_scene_words = 0;
+    rm_vec3 camera{0., 0., 0.};
+
+    // device framebuffer of rm_render
+    double *d_frame = nullptr;
+    size_t frame_bytes = 0;
+    uint32_t frame_w = 0, frame_h = 0;
+
+    // post-process scratch
+    unsigned long long *d_max = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    size_t rgb8_bytes = 0;
+};
+
+static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    else rm_set_host_error(msg);
+    return st;
+}
+
+#define RM_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ctx_fail(ctx, RM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// Scene blob + output slabs must fit beside at least one other workgroup.
+static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 64 * 1024;
+static constexpr size_t RM_LDS_SLAB_BYTES = 4 * 64 * 3 * sizeof(double);
+
+extern "C" {
+
+const char *rm_build_info(void) {
+    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi1";
+}
+
+const char *rm_last_error(const rm_ctx *ctx) {
+    return ctx ? ctx->error.c_str() : rm_get_host_error();
+}
+
+rm_status rm_init(int device_ordinal, rm_ctx **out) {
+    if (!out) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return ctx_fail(nullptr, RM_ERR_NO_DEVICE,
+                        std::string("rm_init: no HIP device visible (") + hipGetErrorString(e) +
+                            "); this backend has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return ctx_fail(nullptr, RM_ERR_NO_DEVICE, "rm_init: device ordinal out of range");
+    rm_ctx *ctx = new rm_ctx();
+    ctx->device = device_ordinal;
+    auto bail = [&](const char *what, hipError_t err) {
+        rm_set_host_error(std::string("rm_init: ") + what + ": " + hipGetErrorString(err));
+        delete ctx;
+        return RM_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipGetDeviceProperties(&ctx->prop, device_ordinal)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    if (std::string(ctx->prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        rm_set_host_error(std::string("rm_init: device is ") + ctx->prop.gcnArchName +
+                          ", this library carries gfx950 code only");
+        delete ctx;
+        return RM_ERR_NO_DEVICE;
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(&ctx->d_max, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    *out = ctx;
+    return RM_OK;
+}
+
+void rm_destroy(rm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_scene) (void)hipFree(ctx->d_scene);
+    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_max) (void)hipFree(ctx->d_max);
+    if (ctx->d_rgb8) (void)hipFree(ctx->d_rgb8);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+rm_status rm_device_info(rm_ctx *ctx, char *name_buf, size_t buflen, int *n_cus, size_t *lds_bytes) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_device_info: NULL ctx");
+    if (name_buf && buflen) std::snprintf(name_buf, buflen, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cus) *n_cus = ctx->prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = ctx->prop.sharedMemPerBlock;
+    return RM_OK;
+}
+
+static uint64_t pack_u32x2(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
+rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_scene_upload: NULL ctx");
+    if (!d) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: NULL desc");
+    if ((d->n_shapes && !d->shapes) || (d->n_spheres && !d->spheres) || (d->n_polygons && !d->polygons) ||
+        (d->n_polygon_vertices && !d->polygon_vertices) || (d->n_triangles && !d->triangles) ||
+        (d->n_lights && !d->lights))
+        return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: NULL array with non-zero count");
+
+    // ---- regroup Scene.shapes by kind, remembering list order for ties ----
+    std::vector<uint32_t> sphere_src, polygon_src, tri_src;   // indices into desc arrays
+    std::vector<uint32_t> sphere_key, polygon_key, tri_key;   // ordinal in flattened list order
+    uint32_t ordinal = 0;
+    for (uint32_t i = 0; i < d->n_shapes; i++) {
+        const rm_shape_ref &r = d->shapes[i];
+        switch (r.kind) {
+        case RM_SHAPE_SPHERE:
+            if (r.first >= d->n_spheres || r.count != 1) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: bad sphere ref");
+            sphere_src.push_back(r.first); sphere_key.push_back(ordinal++);
+            break;
+        case RM_SHAPE_POLYGON:
+            if (r.first >= d->n_polygons || r.count != 1) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: bad polygon ref");
+            polygon_src.push_back(r.first); polygon_key.push_back(ordinal++);
+            break;
+        case RM_SHAPE_MESH:
+            if ((uint64_t)r.first + r.count > d->n_triangles) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: bad mesh ref");
+            for (uint32_t t = 0; t < r.count; t++) { tri_src.push_back(r.first + t); tri_key.push_back(ordinal++); }
+            break;
+        default:
+            return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: unknown shape kind");
+        }
+    }
+    std::vector<uint32_t> keys;
+    keys.insert(keys.end(), sphere_key.begin(), sphere_key.end());
+    keys.insert(keys.end(), polygon_key.begin(), polygon_key.end());
+    keys.insert(keys.end(), tri_key.begin(), tri_key.end());
+    bool ordered = true;
+    for (size_t i = 1; i < keys.size(); i++) ordered = ordered && keys[i - 1] < keys[i];
+
+    rm_dev_header H{};
+    H.n_spheres = (uint32_t)sphere_src.size();
+    H.n_polygons = (uint32_t)polygon_src.size();
+    H.n_triangles = (uint32_t)tri_src.size();
+    H.n_lights = d->n_lights;
+    H.n_prims = H.n_spheres + H.n_polygons + H.n_triangles;
+    H.list_ordered = ordered ? 1u : 0u;
+
+    uint32_t n_pverts = 0, max_nv = 0;
+    for (uint32_t src : polygon_src) {
+        const rm_polygon &p = d->polygons[src];
+        if (p.n_vertices < 3 || (uint64_t)p.first_vertex + p.n_vertices > d->n_polygon_vertices)
+            return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: bad polygon vertex range");
+        n_pverts += p.n_vertices;
+        if (p.n_vertices > max_nv) max_nv = p.n_vertices;
+    }
+    H.max_polygon_vertices = max_nv;
+
+    uint32_t off = 0;
+    auto take = [&](uint32_t words) { uint32_t o = off; off += (words + 1u) & ~1u; return o; };
+    H.off_spheres = take(H.n_spheres * RM_SPHERE_WORDS);
+    H.off_polygons = take(H.n_polygons * RM_POLYGON_WORDS);
+    H.off_pverts = take(n_pverts * RM_PVERT_WORDS);
+    H.off_triangles = take(H.n_triangles * RM_TRIANGLE_WORDS);
+    H.off_materials = take(H.n_prims * RM_MATERIAL_WORDS);
+    H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
+    H.off_keys = take((H.n_prims + 1u) / 2u);
+    H.total_words = off;
+
+    const size_t blob_bytes = (size_t)H.total_words * sizeof(double);
+    if (blob_bytes > RM_LDS_SCENE_LIMIT_BYTES) {
+        char msg[200];
+        std::snprintf(msg, sizeof msg,
+                      "rm_scene_upload: scene needs %zu B of LDS, limit is %zu B (%u primitives, %u lights)", blob_bytes,
+                      RM_LDS_SCENE_LIMIT_BYTES, H.n_prims, H.n_lights);
+        return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, msg);
+    }
+
+    std::vector<double> blob(H.total_words ? H.total_words : 2, 0.);
+    auto put_material = [&](uint32_t pid, const rm_reflectance &r) {
+        double *m = &blob[H.off_materials + RM_MATERIAL_WORDS * pid];
+        m[0] = r.diffusion;
+        m[1] = r.diffuse_color.x; m[2] = r.diffuse_color.y; m[3] = r.diffuse_color.z;
+        m[4] = r.specular; m[5] = r.specular_exponent;
+        m[6] = r.reflection; m[7] = r.refractive_index;
+        m[8] = r.is_glass_like ? 1. : 0.;
+        m[9] = 0.;
+    };
+    uint32_t pid = 0;
+    for (uint32_t i = 0; i < H.n_spheres; i++, pid++) {
+        const rm_sphere &s = d->spheres[sphere_src[i]];
+        double *w = &blob[H.off_spheres + RM_SPHERE_WORDS * i];
+        w[0] = s.center.x; w[1] = s.center.y; w[2] = s.center.z; w[3] = s.radius_square;
+        put_material(pid, s.reflectance);
+    }
+    uint32_t pv = 0;
+    for (uint32_t i = 0; i < H.n_polygons; i++, pid++) {
+        const rm_polygon &p = d->polygons[polygon_src[i]];
+        double *w = &blob[H.off_polygons + RM_POLYGON_WORDS * i];
+        w[0] = p.plane_normal.x; w[1] = p.plane_normal.y; w[2] = p.plane_normal.z;
+        w[3] = p.plane_point.x; w[4] = p.plane_point.y; w[5] = p.plane_point.z;
+        const uint64_t packed = pack_u32x2(pv, p.n_vertices);
+        std::memcpy(&w[6], &packed, sizeof packed);
+        w[7] = 0.;
+        for (uint32_t v = 0; v < p.n_vertices; v++, pv++) {
+            const rm_vec3 &q = d->polygon_vertices[p.first_vertex + v];
+            blob[H.off_pverts + RM_PVERT_WORDS * pv] = q.x;
+            blob[H.off_pverts + RM_PVERT_WORDS * pv + 1] = q.y;
+        }
+        put_material(pid, p.reflectance);
+    }
+    for (uint32_t i = 0; i < H.n_triangles; i++, pid++) {
+        const rm_triangle &t = d->triangles[tri_src[i]];
+        double *w = &blob[H.off_triangles + RM_TRIANGLE_WORDS * i];
+        w[0] = t.normal.x; w[1] = t.normal.y; w[2] = t.normal.z;
+        w[3] = t.center.x; w[4] = t.center.y; w[5] = t.center.z;
+        for (int v = 0; v < 3; v++) { w[6 + 2 * v] = t.vertices[v].x; w[7 + 2 * v] = t.vertices[v].y; }
+        put_material(pid, t.reflectance);
+    }
+    for (uint32_t l = 0; l < H.n_lights; l++) {
+        const rm_light &lt = d->lights[l];
+        double *w = &blob[H.off_lights + RM_LIGHT_WORDS * l];
+        w[0] = lt.position.x; w[1] = lt.position.y; w[2] = lt.position.z;
+        w[3] = lt.color.x; w[4] = lt.color.y; w[5] = lt.color.z;
+        w[6] = lt.intensity; w[7] = 0.;
+    }
+    if (!keys.empty()) std::memcpy(&blob[H.off_keys], keys.data(), keys.size() * sizeof(uint32_t));
+
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a render may still be reading the old blob
+    if (ctx->d_scene_words < blob.size()) {
+        if (ctx->d_scene) RM_HIP(ctx, hipFree(ctx->d_scene));
+        ctx->d_scene = nullptr;
+        RM_HIP(ctx, hipMalloc(&ctx->d_scene, blob.size() * sizeof(double)));
+        ctx->d_scene_words = blob.size();
+    }
+    RM_HIP(ctx, hipMemcpy(ctx->d_scene, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->H = H;
+    ctx->camera = d->camera;
+    ctx->have_scene = true;
+    return RM_OK;
+}
+
+rm_status rm_camera_update(rm_ctx *ctx, rm_vec3 camera) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_camera_update: NULL ctx");
+    if (!ctx->have_scene) return ctx_fail(ctx, RM_ERR_NO_SCENE, "rm_camera_update: no scene uploaded");
+    ctx->camera = camera;   // the camera travels as a kernel argument
+    return RM_OK;
+}
+
+// Validates params and computes the band; shared by both render entry points.
+static rm_status check_params(rm_ctx *ctx, const rm_params *p, uint32_t *row_begin, uint32_t *row_end) {
+    if (!p) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: NULL params");
+    if (!ctx->have_scene) return ctx_fail(ctx, RM_ERR_NO_SCENE, "render: no scene uploaded (rm_scene_upload)");
+    if (p->patch_size != RM_PATCH_SIZE) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: patch_size must be 32 (renderer.rs:47)");
+    if (p->max_depth > RM_MAX_DEPTH) return ctx_fail(ctx, RM_ERR_DEPTH, "render: max_depth above RM_MAX_DEPTH");
+    if (p->frame_width == 0 || p->frame_height == 0) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: empty frame");
+    if (p->frame_width % RM_PATCH_SIZE != 0)
+        return ctx_fail(ctx, RM_ERR_DIMENSIONS,
+                        "render: frame width is not a multiple of 32; the reference's scatter "
+                        "(renderer.rs:92-108) indexes out of bounds and panics");
+    const uint32_t n_height = p->frame_height / RM_PATCH_SIZE;   // renderer.rs:53: bottom H%32 rows never rendered
+    uint32_t b = p->patch_row_begin, e = p->patch_row_end == 0 ? n_height : p->patch_row_end;
+    if (e > n_height) e = n_height;
+    if (b > e) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: patch_row_begin > patch_row_end");
+    *row_begin = b;
+    *row_end = e;
+    return RM_OK;
+}
+
+static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_begin, uint32_t row_end, double *d_frame,
+                               hipStream_t stream) {
+    if (row_begin == row_end) return RM_OK;
+    const uint32_t n_width = p->frame_width / RM_PATCH_SIZE;
+    if (p->max_depth == 0) {
+        const size_t first_px = (size_t)row_begin * 32u * p->frame_width;
+        const size_t n_px = (size_t)(row_end - row_begin) * 32u * p->frame_width;
+        hipLaunchKernelGGL(rm_fill_band_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, d_frame,
+                           first_px, n_px, p->background.x, p->background.y, p->background.z);
+        RM_HIP(ctx, hipGetLastError());
+        return RM_OK;
+    }
+    KernelArgs a{};
+    a.H = ctx->H;
+    a.half_fov = p->half_fov; a.height = p->height; a.width = p->width; a.ratio = p->ratio;
+    a.cam_x = ctx->camera.x; a.cam_y = ctx->camera.y; a.cam_z = ctx->camera.z;
+    a.bg_x = p->background.x; a.bg_y = p->background.y; a.bg_z = p->background.z;
+    a.frame_width = p->frame_width;
+    a.patch_row_begin = row_begin;
+    a.max_depth = p->max_depth;
+    const size_t lds = (size_t)ctx->H.total_words * sizeof(double) + RM_LDS_SLAB_BYTES;
+    const dim3 grid(n_width, row_end - row_begin), block(256);
+    // The walk descends into the refracted child directly and parks the reflected one:
+    // at most one pending sibling per level below the cap, i.e. max_depth - 1 entries.
+    if (p->max_depth <= 5)
+        hipLaunchKernelGGL(rm_render_kernel<4>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
+    else if (p->max_depth <= 9)
+        hipLaunchKernelGGL(rm_render_kernel<8>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
+    else if (p->max_depth <= 17)
+        hipLaunchKernelGGL(rm_render_kernel<16>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
+    else
+        hipLaunchKernelGGL(rm_render_kernel<32>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
+    RM_HIP(ctx, hipGetLastError());
+    return RM_OK;
+}
+
+rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render_device: NULL ctx");
+    if (!device_rgb) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render_device: NULL device buffer");
+    uint32_t b = 0, e = 0;
+    rm_status st = check_params(ctx, params, &b, &e);
+    if (st != RM_OK) return st;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return launch_render(ctx, params, b, e, (double *)device_rgb, s);
+}
+
+rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render: NULL ctx");
+    const auto t_begin = std::chrono::steady_clock::now();
+    uint32_t b = 0, e = 0;
+    rm_status st = check_params(ctx, params, &b, &e);
+    if (st != RM_OK) return st;
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+
+    const size_t need = (size_t)params->frame_width * params->frame_height * 3u * sizeof(double);
+    if (ctx->frame_bytes != need || ctx->frame_w != params->frame_width || ctx->frame_h != params->frame_height) {
+        RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_frame) RM_HIP(ctx, hipFree(ctx->d_frame));
+        ctx->d_frame = nullptr;
+        ctx->frame_bytes = 0;
+        RM_HIP(ctx, hipMalloc(&ctx->d_frame, need));
+        // create_frame_buffer zero-fills (framebuffer.rs:12-22)
+        RM_HIP(ctx, hipMemsetAsync(ctx->d_frame, 0, need, ctx->stream));
+        ctx->frame_bytes = need;
+        ctx->frame_w = params->frame_width;
+        ctx->frame_h = params->frame_height;
+    }
+
+    RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    st = launch_render(ctx, params, b, e, ctx->d_frame, ctx->stream);
+    if (st != RM_OK) return st;
+    RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+
+    double d2h_ms = 0.;
+    if (host_rgb && e > b) {
+        // Only the band's rows are copied: rows below the last whole patch row keep the
+        // caller's previous contents, as in the reference (renderer.rs:53).
+        const size_t row_bytes = (size_t)params->frame_width * 3u * sizeof(double);
+        const size_t off = (size_t)b * 32u * row_bytes;
+        const size_t len = (size_t)(e - b) * 32u * row_bytes;
+        RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        RM_HIP(ctx, hipMemcpy((char *)host_rgb + off, (const char *)ctx->d_frame + off, len, hipMemcpyDeviceToHost));
+        d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (timing) {
+        float ms = 0.f;
+        RM_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        timing->kernel_ms = ms;
+        timing->d2h_ms = d2h_ms;
+        timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return RM_OK;
+}
+
+rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_device_framebuffer: NULL ctx");
+    if (!ctx->d_frame) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_device_framebuffer: nothing rendered yet");
+    if (device_rgb) *device_rgb = ctx->d_frame;
+    if (bytes) *bytes = ctx->frame_bytes;
+    return RM_OK;
+}
+
+rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, int normalize, uint8_t *host_rgb8,
+                         double *max_out) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_postprocess: NULL ctx");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    double *v = (double *)device_rgb;
+    if (!v) {
+        if (!ctx->d_frame) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_postprocess: nothing rendered yet");
+        if (w != ctx->frame_w || h != ctx->frame_h)
+            return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_postprocess: size differs from the rendered frame");
+        v = ctx->d_frame;
+    }
+    const size_t n = (size_t)w * h * 3u;
+    if (n == 0) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_postprocess: empty frame");
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    RM_HIP(ctx, hipMemsetAsync(ctx->d_max, 0, sizeof(unsigned long long), ctx->stream));
+    if (normalize) {
+        hipLaunchKernelGGL(rm_max_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v, n, ctx->d_max);
+        RM_HIP(ctx, hipGetLastError());
+    }
+    uint8_t *d8 = nullptr;
+    if (host_rgb8) {
+        if (ctx->rgb8_bytes < n) {
+            RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_rgb8) RM_HIP(ctx, hipFree(ctx->d_rgb8));
+            ctx->d_rgb8 = nullptr;
+            ctx->rgb8_bytes = 0;
+            RM_HIP(ctx, hipMalloc(&ctx->d_rgb8, n));
+            ctx->rgb8_bytes = n;
+        }
+        d8 = ctx->d_rgb8;
+    }
+    if (normalize || d8) {
+        hipLaunchKernelGGL(rm_scale_quantize_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v, n, ctx->d_max,
+                           normalize ? 1 : 0, d8);
+        RM_HIP(ctx, hipGetLastError());
+    }
+    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (host_rgb8) RM_HIP(ctx, hipMemcpy(host_rgb8, d8, n, hipMemcpyDeviceToHost));
+    if (max_out) {
+        unsigned long long bits = 0;
+        RM_HIP(ctx, hipMemcpy(&bits, ctx->d_max, sizeof bits, hipMemcpyDeviceToHost));
+        std::memcpy(max_out, &bits, sizeof bits);
+    }
+    return RM_OK;
+}
+
+}  // extern "C"

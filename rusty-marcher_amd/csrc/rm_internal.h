@@ -1,0 +1,45 @@
+// rm_internal.h -- shared between the host (rm_scene.cpp) and device (rm_device.hip)
+// halves of librusty_marcher_amd.so.  Not part of the public ABI.
+#ifndef RM_INTERNAL_H
+#define RM_INTERNAL_H
+
+#include "rusty_marcher_amd.h"
+
+#include <string>
+
+// thread-local error text for calls that have no rm_ctx (scene builder, rm_init)
+void rm_set_host_error(const std::string &msg);
+const char *rm_get_host_error();
+
+// ---- device scene blob --------------------------------------------------
+// The uploaded scene is one array of 8-byte words that every workgroup copies
+// into LDS.  Primitives are regrouped by kind; `pid` (device primitive id) is
+// the position in [spheres | polygons | triangles].  All offsets are in
+// 8-byte words from the start of the blob and are multiples of 2 so that
+// 16-byte LDS reads stay aligned.
+//
+//   spheres   4 words each : cx cy cz r^2                       (sphere.rs:6-11)
+//   polygons  8 words each : nx ny nz  ppx ppy ppz  {first_vertex,n_vertices}  0
+//   pverts    2 words each : x y       (polygon.rs:54-56 reads only .z of the cross
+//                                       product, i.e. only x and y of the vertices)
+//   triangles 12 words each: nx ny nz  cx cy cz  v0x v0y v1x v1y v2x v2y
+//   materials 10 words per pid: diffusion dcx dcy dcz specular exponent
+//                               reflection refractive_index is_glass 0
+//   lights    8 words each : px py pz  cx cy cz  intensity 0
+//   keys      1 u32 per pid (2 per word): position in Scene.shapes order, used
+//                               only to break exact distance ties (shapes.rs:130)
+struct rm_dev_header {
+    uint32_t n_spheres, n_polygons, n_triangles, n_lights;
+    uint32_t off_spheres, off_polygons, off_pverts, off_triangles;
+    uint32_t off_materials, off_lights, off_keys, total_words;
+    uint32_t n_prims, list_ordered, max_polygon_vertices, _pad;
+};
+
+#define RM_SPHERE_WORDS 4u
+#define RM_POLYGON_WORDS 8u
+#define RM_PVERT_WORDS 2u
+#define RM_TRIANGLE_WORDS 12u
+#define RM_MATERIAL_WORDS 10u
+#define RM_LIGHT_WORDS 8u
+
+#endif
