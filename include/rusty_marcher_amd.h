@@ -211,7 +211,8 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
 /*
  * Same kernel, asynchronous, into a caller-owned DEVICE buffer with the same
  * [frame_height][frame_width][3] layout, enqueued on `hip_stream` (a hipStream_t;
- * NULL = the context's stream).  Returns once enqueued.
+ * NULL = HIP's default stream).  Returns once enqueued; ordering with the caller's
+ * other work is that stream's.
  */
 rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream);
 

@@ -10,6 +10,7 @@
 #include <assert.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -605,9 +606,38 @@ static void *worker(void *arg)
     return NULL;
 }
 
+/* Threads this process may actually run on: the affinity mask, further limited by
+ * a cgroup CPU quota when one is set (a container's share of a bigger host). */
 int orc_online_cpus(void)
 {
     long n = sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        int c = CPU_COUNT(&set);
+        if (c > 0 && c < n) n = c;
+    }
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        long quota = 0, period = 0;
+        if (fscanf(f, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            long q = (quota + period - 1) / period;
+            if (q > 0 && q < n) n = q;
+        }
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {
+        long quota = 0, period = 100000;
+        if (fscanf(f, "%ld", &quota) != 1) quota = 0;
+        fclose(f);
+        FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (g) {
+            if (fscanf(g, "%ld", &period) != 1) period = 100000;
+            fclose(g);
+        }
+        if (quota > 0 && period > 0) {
+            long q = (quota + period - 1) / period;
+            if (q > 0 && q < n) n = q;
+        }
+    }
     return n > 0 ? (int)n : 1;
 }
 

@@ -128,6 +128,12 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `make -C rusty-marcher_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: the PyTorch wheel carries its own libamdhip64.so.7.
+        # Importing torch first makes the dynamic loader resolve this library's
+        # NEEDED libamdhip64.so.7 to that already-loaded copy (same SONAME), so device
+        # pointers and streams are shared with torch.  Loaded the other way round, the
+        # process would hold two runtimes and the second finds no device.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

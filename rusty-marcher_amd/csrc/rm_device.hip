@@ -536,7 +536,7 @@ rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rg
     rm_status st = check_params(ctx, params, &b, &e);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = (hipStream_t)hip_stream;   // NULL is HIP's default stream, as in any HIP API
     return launch_render(ctx, params, b, e, (double *)device_rgb, s);
 }
 

@@ -98,14 +98,17 @@ class Scene:
                           Vec3f(l.color.x, l.color.y, l.color.z), l.intensity)
                     for l in (d.lights[i] for i in range(d.n_lights))]
         s._prebuilt = handle
-        s._prebuilt_sig = None
+        s._prebuilt_lights = list(s.lights)
         s.shapes = _PrebuiltShapes(handle)
         return s
 
     def flatten(self):
         """-> SceneHandle with the current lights / shapes / camera."""
         L = _lib.lib()
-        if self._prebuilt is not None and isinstance(self.shapes, _PrebuiltShapes) and not self.shapes.touched:
+        untouched = (self._prebuilt is not None and isinstance(self.shapes, _PrebuiltShapes)
+                     and not self.shapes.touched and len(self.lights) == len(self._prebuilt_lights)
+                     and all(a is b for a, b in zip(self.lights, self._prebuilt_lights)))
+        if untouched:
             _lib.check(L.rm_scene_set_camera(self._prebuilt.ptr, _lib.vec3(self.camera)))
             return self._prebuilt
         h = C.c_void_p()

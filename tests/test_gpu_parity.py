@@ -1,0 +1,453 @@
+"""GPU parity tests proper (-m gpu): the HIP render path, called through the C ABI,
+against the CPU oracle on the same inputs, the committed golden file, and
+size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: BASELINE.json's north star asks per-channel |delta| < 1e-4 on every pixel.
+The kernel computes in binary64 in the reference's operation order, so the tests also
+hold it to TIGHT = 1e-9 (the only non-identical operation is pow: device libm vs glibc).
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_TOL = 1e-4
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    c = pkg.backend.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_render(pkg, ctx, scene, w, h, depth, band=None, out=None, fov=workloads.FOV):
+    handle = scene.flatten()
+    ctx.upload(handle)
+    p = pkg.backend.make_params(fov, float(h), float(w), depth, band)
+    if out is None:
+        out = np.zeros((h, w, 3), dtype=np.float64)
+    t = ctx.render(p, out)
+    return out, t
+
+
+def compare(gpu, ref, tol=TIGHT):
+    d = np.abs(gpu - ref)
+    worst = float(d.max())
+    n_loose = int((d > 1e-12).sum())
+    assert worst < NORTH_STAR_TOL, "max |delta| %.3e breaks the north-star tolerance" % worst
+    assert worst < tol, "max |delta| %.3e (channels above 1e-12: %d)" % (worst, n_loose)
+    return worst
+
+
+# ---------------------------------------------------------------- golden + configs
+def test_demo_800x600_against_oracle_and_out_ppm(pkg, O, ctx, golden_ppm):
+    """The reference's own committed render: GPU frame -> device normalize + quantize
+    (rm_postprocess) -> PPM bytes, compared with engine/out.ppm."""
+    gpu, _ = gpu_render(pkg, ctx, pkg.Scene.create_default(), 800, 600, 3)
+    ref = O.render(O.OracleScene.create_default(), 800, 600, max_depth=3)
+    compare(gpu, ref)
+    assert np.all(gpu[576:] == 0.)
+
+    out8 = np.empty(800 * 600 * 3, dtype=np.uint8)
+    mx = C.c_double()
+    pkg._lib.check(pkg.lib().rm_postprocess(ctx.ptr, None, 800, 600, 1,
+                                            out8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(mx)), ctx.ptr)
+    assert abs(mx.value - 2.3621674603868565) < 1e-12
+    data = b"P6\n800 600\n255\n" + out8.tobytes()
+    n_diff = int((np.frombuffer(data, np.uint8) != np.frombuffer(golden_ppm, np.uint8)).sum())
+    # u8 truncation can flip a byte when a channel sits within an ulp of k/255
+    assert n_diff <= 2, "%d of 1,440,015 bytes differ from the reference's out.ppm" % n_diff
+    if n_diff == 0:
+        assert hashlib.sha256(data).hexdigest() == "82d51afaaf4a644547728dde89478e484c245d2e3eb1e40da8b928ebd7584797"
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C3"])
+def test_config_full_frame(pkg, O, ctx, cfg):
+    c = workloads.CONFIGS[cfg]
+    gpu, _ = gpu_render(pkg, ctx, workloads.product_scene(pkg, c["scene"]), c["width"], c["height"], c["max_depth"])
+    ref = O.render(workloads.oracle_scene(O, c["scene"]), c["width"], c["height"], max_depth=c["max_depth"])
+    compare(gpu, ref)
+    assert (gpu.sum(axis=2) > 0).mean() > 0.1
+    if c["height"] % 32:
+        assert np.all(gpu[c["height"] - c["height"] % 32:] == 0.)     # 1080 % 32 = 24 rows untouched
+
+
+def test_config_c4_8k(pkg, O, ctx):
+    c = workloads.CONFIGS["C4"]
+    w, h = c["width"], c["height"]
+    gpu, _ = gpu_render(pkg, ctx, pkg.Scene.create_default(), w, h, c["max_depth"])
+    ref = O.render(O.OracleScene.create_default(), w, h, max_depth=c["max_depth"])
+    np.subtract(gpu, ref, out=ref)
+    np.abs(ref, out=ref)
+    worst = float(ref.max())
+    assert worst < TIGHT, worst
+
+
+def test_config_c5_synthetic_bands(pkg, O, ctx):
+    """4096x4096, 256 spheres, depth 10: the oracle needs minutes for the full frame,
+    so eight patch rows spread over the image are checked pixel for pixel; the rest is
+    covered by the property tests below."""
+    c = workloads.CONFIGS["C5"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    gpu, _ = gpu_render(pkg, ctx, workloads.product_scene(pkg, "synthetic256"), w, h, depth)
+    so = workloads.oracle_scene(O, "synthetic256")
+    ref = np.zeros((h, w, 3), dtype=np.float64)
+    rows = [0, 23, 47, 64, 77, 96, 111, 127]
+    for r in rows:
+        O.render(so, w, h, max_depth=depth, frame=ref, band=(r, r + 1))
+        compare(gpu[r * 32:(r + 1) * 32], ref[r * 32:(r + 1) * 32])
+    assert (gpu.sum(axis=2) > 0).mean() > 0.3
+
+
+def test_synthetic_small_full_frame(pkg, O, ctx):
+    gpu, _ = gpu_render(pkg, ctx, workloads.product_scene(pkg, "synthetic256"), 512, 384, 10)
+    ref = O.render(workloads.oracle_scene(O, "synthetic256"), 512, 384, max_depth=10)
+    compare(gpu, ref)
+
+
+# ---------------------------------------------------------------- depth caps
+@pytest.mark.parametrize("depth", [0, 1, 2, 3, 4, 6, 9, 10, 17, 18, 32])
+def test_depth_caps(pkg, O, ctx, depth):
+    gpu, _ = gpu_render(pkg, ctx, pkg.Scene.create_default(), 320, 256, depth)
+    ref = O.render(O.OracleScene.create_default(), 320, 256, max_depth=depth)
+    compare(gpu, ref)
+    if depth == 0:
+        assert np.all(gpu == 0.1)       # renderer.rs:262-264 with n_recursion = 1
+
+
+def test_deep_recursion_needs_the_stack(pkg, O, ctx):
+    """A stack of 13 glass panes in front of a glass sphere: every pane adds a level
+    (refraction) and, at oblique incidence, a sibling (reflection), so the ray trees
+    really reach the caps being tested and the per-lane stack is exercised."""
+    glass = dict(diffusion=0.3, diffuse_color=(0.9, 0.8, 0.7), specular=0.9, specular_exponent=20.,
+                 is_glass_like=True, reflection=0.4, refractive_index=1.5)
+    panes = []
+    for k in range(13):
+        z = -4. - 1.25 * k
+        tilt = 0.05 * k
+        panes.append([(-12., -9., z - tilt), (12., -9., z + tilt), (12., 9., z + tilt), (-12., 9., z - tilt)])
+
+    def prod():
+        s = pkg.Scene.new()
+        R = pkg.Reflectance(**glass)
+        V = pkg.Vec3f
+        for q in panes:
+            s.shapes.append(pkg.polygon.ConvexPolygon.create([V(*p) for p in q], R))
+        s.shapes.append(pkg.sphere.create(V(1.5, 0.5, -30.), 6., R))
+        s.lights.append(pkg.create_light(V(0., 10., 0.), V(1., 1., 1.), 1.))
+        return s
+
+    def orc():
+        s = O.OracleScene()
+        R = O.reflectance(**glass)
+        for q in panes:
+            s.add_polygon(q, R)
+        s.add_sphere((1.5, 0.5, -30.), 6., R)
+        s.add_light((0., 10., 0.), (1., 1., 1.), 1.)
+        return s
+
+    refs = {}
+    for depth in (5, 10, 16, 32):
+        gpu, _ = gpu_render(pkg, ctx, prod(), 256, 224, depth)
+        refs[depth] = O.render(orc(), 256, 224, max_depth=depth)
+        compare(gpu, refs[depth])
+    assert not np.array_equal(refs[10], refs[16])       # levels above 10 are really reached
+    assert not np.array_equal(refs[5], refs[10])
+
+
+# ---------------------------------------------------------------- edge cases
+def test_bottom_rows_keep_previous_contents(pkg, O, ctx):
+    """renderer.rs:53: H % 32 bottom rows are never written -- stale pixels survive."""
+    out = np.full((100, 64, 3), 7.25)
+    gpu, _ = gpu_render(pkg, ctx, pkg.Scene.create_default(), 64, 100, 3, out=out)
+    assert np.all(gpu[96:] == 7.25)
+    ref = O.render(O.OracleScene.create_default(), 64, 100, max_depth=3, frame=np.full((100, 64, 3), 7.25))
+    compare(gpu, ref)
+
+
+def test_width_not_multiple_of_32_is_the_reference_panic(pkg, ctx):
+    ctx.upload(pkg.Scene.create_default().flatten())
+    p = pkg.backend.make_params(1.5, 64., 100.)
+    with pytest.raises(pkg.BackendError) as e:
+        ctx.render(p, np.zeros((64, 100, 3)))
+    assert e.value.status == pkg._lib.RM_ERR_DIMENSIONS
+
+
+def test_render_before_upload_and_bad_params(pkg):
+    c = pkg.backend.Context(0)
+    try:
+        p = pkg.backend.make_params(1.5, 64., 64.)
+        with pytest.raises(pkg.BackendError) as e:
+            c.render(p, np.zeros((64, 64, 3)))
+        assert e.value.status == pkg._lib.RM_ERR_NO_SCENE
+        c.upload(pkg.Scene.create_default().flatten())
+        p.max_depth = 33
+        with pytest.raises(pkg.BackendError) as e:
+            c.render(p, np.zeros((64, 64, 3)))
+        assert e.value.status == pkg._lib.RM_ERR_DEPTH
+        p.max_depth = 3
+        p.patch_size = 16
+        with pytest.raises(pkg.BackendError):
+            c.render(p, np.zeros((64, 64, 3)))
+    finally:
+        c.close()
+
+
+def test_height_below_one_patch_renders_nothing(pkg, ctx):
+    out = np.full((20, 64, 3), -1.)
+    gpu, _ = gpu_render(pkg, ctx, pkg.Scene.create_default(), 64, 20, 3, out=out)
+    assert np.all(gpu == -1.)
+
+
+def test_empty_scene_and_no_lights(pkg, O, ctx):
+    gpu, _ = gpu_render(pkg, ctx, pkg.Scene.new(), 64, 64, 3)
+    assert np.all(gpu == 0.)                                     # primary miss: zero, renderer.rs:305
+    s = pkg.Scene.create_default()
+    s.lights = []
+    so = O.OracleScene.create_default()
+    so.c.n_lights = 0
+    gpu, _ = gpu_render(pkg, ctx, s, 128, 96, 3)
+    ref = O.render(so, 128, 96, max_depth=3)
+    compare(gpu, ref)
+
+
+def test_camera_offsets(pkg, O, ctx):
+    """scene.rs:25-27 / main.rs:75-78: +-5 steps; second render goes through
+    rm_camera_update without re-upload."""
+    s = pkg.Scene.create_default()
+    so = O.OracleScene.create_default()
+    cam = np.zeros(3)
+    for off in [(0., 0., 5.), (-5., 0., 0.), (0., 5., 0.), (0., 0., -15.)]:
+        s.offset_camera(pkg.Vec3f(*off))
+        cam += off
+        so.set_camera(tuple(cam))
+        gpu, _ = gpu_render(pkg, ctx, s, 256, 160, 3)
+        compare(gpu, O.render(so, 256, 160, max_depth=3))
+    ctx.set_camera((1., 2., 3.))
+    so.set_camera((1., 2., 3.))
+    out = np.zeros((160, 256, 3))
+    ctx.render(pkg.backend.make_params(1.5, 160., 256.), out)
+    compare(out, O.render(so, 256, 160, max_depth=3))
+
+
+def test_renderer_dimensions_differ_from_frame(pkg, O, ctx):
+    """backproject uses the Renderer's own width/height (renderer.rs:130-131), not the
+    FrameBuffer's: render a 128x96 frame with a renderer created for 256x192."""
+    ctx.upload(pkg.Scene.create_default().flatten())
+    p = pkg.backend.make_params(1.2, 192., 256.)
+    p.frame_width, p.frame_height = 128, 96
+    out = np.zeros((96, 128, 3))
+    ctx.render(p, out)
+    L = O.lib()
+    r = L.orc_create_renderer(1.2, 192., 256.)
+    ref = np.zeros((96, 128, 3))
+    so = O.OracleScene.create_default()
+    rc = L.orc_render(C.byref(r), so.ptr, ref.ctypes.data_as(C.POINTER(C.c_double)), 128, 96, 3, 0, None)
+    assert rc == 0
+    compare(out, ref)
+
+
+def test_exact_ties_follow_list_order(pkg, O, ctx):
+    """shapes.rs:130: strict `<` -- the first shape in the list wins an exact distance
+    tie.  Coincident spheres of different colours, interleaved with a mesh so that the
+    device's grouping by kind differs from list order."""
+    tri = np.array([[-30., -30., -40., 30., -30., -40., 0., 30., -40.]])
+
+    def prod(order):
+        s = pkg.Scene.new()
+        V = pkg.Vec3f
+        items = {
+            "red": lambda: pkg.sphere.create(V(0., 0., -10.), 3., pkg.Reflectance(diffuse_color=(1., 0., 0.))),
+            "green": lambda: pkg.sphere.create(V(0., 0., -10.), 3., pkg.Reflectance(diffuse_color=(0., 1., 0.))),
+            "mesh": lambda: pkg.obj.Obj(tri),
+            "mesh2": lambda: pkg.obj.Obj(tri),
+        }
+        for k in order:
+            s.shapes.append(items[k]())
+        s.lights.append(pkg.create_light(V(0., 0., 0.), V(1., 1., 1.), 1.))
+        return s
+
+    def orc(order):
+        s = O.OracleScene()
+        for k in order:
+            if k == "red":
+                s.add_sphere((0., 0., -10.), 3., O.reflectance(diffuse_color=(1., 0., 0.)))
+            elif k == "green":
+                s.add_sphere((0., 0., -10.), 3., O.reflectance(diffuse_color=(0., 1., 0.)))
+            else:
+                s.add_obj(tri)
+        s.add_light((0., 0., 0.), (1., 1., 1.), 1.)
+        return s
+
+    centre = {}
+    for order in (["red", "mesh", "green", "mesh2"], ["green", "mesh", "red", "mesh2"], ["mesh", "mesh2", "green", "red"]):
+        gpu, _ = gpu_render(pkg, ctx, prod(order), 128, 128, 3)
+        compare(gpu, O.render(orc(order), 128, 128, max_depth=3))
+        centre[tuple(order)] = gpu[64, 64]
+    assert centre[("red", "mesh", "green", "mesh2")][0] > centre[("red", "mesh", "green", "mesh2")][1]
+    assert centre[("green", "mesh", "red", "mesh2")][1] > centre[("green", "mesh", "red", "mesh2")][0]
+
+
+def test_polygon_winding_and_edge_on(pkg, O, ctx):
+    """polygon.rs:54-56: 2-D inside test in the XY projection, counter-clockwise only;
+    clockwise and edge-on (to z) polygons never hit."""
+    ccw = [(-4., -3., -12.), (4., -3., -10.), (5., 3., -9.), (0., 5., -11.), (-5., 2., -13.)]
+    cw = list(reversed(ccw))
+    edge_on = [(0., -3., -5.), (0., 3., -5.), (0., 3., -15.), (0., -3., -15.)]
+    for verts in (ccw, cw, edge_on):
+        s = pkg.Scene.new()
+        s.shapes.append(pkg.polygon.ConvexPolygon.create([pkg.Vec3f(*p) for p in verts],
+                                                         pkg.Reflectance(diffuse_color=(0.5, 0.6, 0.7))))
+        s.lights.append(pkg.create_light(pkg.Vec3f(2., 3., 0.), pkg.Vec3f(1., 1., 1.), 1.))
+        so = O.OracleScene()
+        so.add_polygon(verts, O.reflectance(diffuse_color=(0.5, 0.6, 0.7)))
+        so.add_light((2., 3., 0.), (1., 1., 1.), 1.)
+        gpu, _ = gpu_render(pkg, ctx, s, 160, 128, 3)
+        ref = O.render(so, 160, 128, max_depth=3)
+        compare(gpu, ref)
+        assert (gpu.sum() > 0) == (verts is ccw)
+
+
+def test_shadow_from_occluder_behind_the_light(pkg, O, ctx):
+    """renderer.rs:174: the any-hit test is not limited to the light's distance."""
+    def mk(with_blocker):
+        s, so = pkg.Scene.new(), O.OracleScene()
+        V = pkg.Vec3f
+        s.shapes.append(pkg.sphere.create(V(0., 0., -10.), 2., pkg.Reflectance.create_default()))
+        so.add_sphere((0., 0., -10.), 2., O.reflectance())
+        if with_blocker:      # beyond the light, as seen from the lit sphere
+            s.shapes.append(pkg.sphere.create(V(0., 30., -10.), 4., pkg.Reflectance.create_default()))
+            so.add_sphere((0., 30., -10.), 4., O.reflectance())
+        s.lights.append(pkg.create_light(V(0., 10., -10.), V(1., 1., 1.), 1.))
+        so.add_light((0., 10., -10.), (1., 1., 1.), 1.)
+        return s, so
+    s, so = mk(True)
+    gpu, _ = gpu_render(pkg, ctx, s, 128, 128, 3)
+    compare(gpu, O.render(so, 128, 128, max_depth=3))
+    s2, _ = mk(False)
+    lit, _ = gpu_render(pkg, ctx, s2, 128, 128, 3)
+    assert lit[50, 64].sum() > gpu[50, 64].sum()      # the far sphere shadows the near one
+
+
+def test_scene_too_large_for_lds_is_reported(pkg, ctx):
+    s = pkg.Scene.new()
+    tri = np.random.default_rng(0).uniform(-1, 1, size=(600, 9))
+    s.shapes.append(pkg.obj.Obj(tri))
+    with pytest.raises(pkg.BackendError) as e:
+        ctx.upload(s.flatten())
+    assert e.value.status == pkg._lib.RM_ERR_SCENE_LIMIT
+    ctx.upload(pkg.Scene.create_default().flatten())         # context stays usable
+
+
+# ---------------------------------------------------------------- properties at full size
+def test_bands_tile_the_frame_bitwise(pkg, ctx):
+    """Row sharding: the union of per-rank bands is bit-identical to the
+    single-GPU frame, for even and uneven splits, at the 8K configuration."""
+    c = workloads.CONFIGS["C4"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    scene = pkg.Scene.create_default()
+    full, _ = gpu_render(pkg, ctx, scene, w, h, depth)
+    n_rows = h // 32
+    for world in (8, 3):
+        parts = np.zeros_like(full)
+        for r in range(world):
+            band = workloads.patch_rows_for_rank(n_rows, r, world)
+            gpu_render(pkg, ctx, scene, w, h, depth, band=band, out=parts)
+        assert np.array_equal(full, parts)
+    assert [workloads.patch_rows_for_rank(135, r, 8) for r in range(8)][-1] == (118, 135)
+
+
+def test_render_is_deterministic(pkg, ctx):
+    c = workloads.CONFIGS["C2"]
+    scene = pkg.Scene.create_default()
+    a, _ = gpu_render(pkg, ctx, scene, c["width"], c["height"], c["max_depth"])
+    b, _ = gpu_render(pkg, ctx, scene, c["width"], c["height"], c["max_depth"])
+    assert np.array_equal(a, b)
+
+
+def test_depth_caps_beyond_natural_depth_agree_at_full_size(pkg, ctx):
+    """the demo ray tree ends at depth 4, so caps 5, 8 and 10 give the same
+    image; cap 3 differs."""
+    scene = pkg.Scene.create_default()
+    frames = {d: gpu_render(pkg, ctx, scene, 1920, 1080, d)[0] for d in (3, 5, 8, 10)}
+    assert np.array_equal(frames[5], frames[8]) and np.array_equal(frames[8], frames[10])
+    assert not np.array_equal(frames[3], frames[5])
+
+
+def test_render_device_into_torch_buffer(pkg, O, ctx):
+    """rm_render_device: caller-owned device memory + caller's stream (the path bench.py
+    and the multi-GPU gather use)."""
+    import torch
+    w, h = 640, 352
+    ctx.upload(pkg.Scene.create_default().flatten())
+    buf = torch.full((h, w, 3), -3., dtype=torch.float64, device="cuda:0")
+    stream = torch.cuda.Stream()
+    p = pkg.backend.make_params(1.5, float(h), float(w), 5, band=(2, 9))
+    with torch.cuda.stream(stream):
+        ctx.render_device(p, buf.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    got = buf.cpu().numpy()
+    ref = np.full((h, w, 3), -3.)
+    O.render(O.OracleScene.create_default(), w, h, max_depth=5, frame=ref, band=(2, 9))
+    compare(got, ref)
+    assert np.all(got[:64] == -3.) and np.all(got[288:] == -3.)
+
+
+# ---------------------------------------------------------------- post-process (8f.1)
+def test_postprocess_normalize_and_quantize(pkg, O, ctx):
+    import torch
+    rng = np.random.default_rng(3)
+    frame = rng.uniform(-0.5, 3.0, size=(96, 160, 3))
+    frame[5, 7, 1] = np.nan
+    frame[9, 9] = [0., 1., 255. / 255.]
+    for normalize in (0, 1):
+        dev = torch.from_numpy(frame.copy()).cuda()
+        out8 = np.empty(frame.size, dtype=np.uint8)
+        mx = C.c_double()
+        pkg._lib.check(pkg.lib().rm_postprocess(ctx.ptr, C.c_void_p(dev.data_ptr()), 160, 96, normalize,
+                                                out8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(mx)), ctx.ptr)
+        ref = frame.copy()
+        if normalize:
+            O.normalize(ref)
+            assert mx.value == np.nanmax(frame)
+            got = dev.cpu().numpy()
+            assert np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+        assert np.array_equal(out8, O.to_vec(ref))
+    # all-zero frame: max == 0 leaves it untouched (framebuffer.rs:69)
+    dev = torch.zeros((32, 32, 3), dtype=torch.float64, device="cuda")
+    pkg._lib.check(pkg.lib().rm_postprocess(ctx.ptr, C.c_void_p(dev.data_ptr()), 32, 32, 1, None, None), ctx.ptr)
+    assert float(dev.abs().max()) == 0.
+
+
+# ---------------------------------------------------------------- reference-shaped surface
+def test_reference_call_sequence(pkg, O, capsys):
+    """main.rs:119-123 + 329-357: default scene, create_renderer(1.5, h, w), render,
+    normalize, write_ppm -- through the Python mirror of the reference's API."""
+    fb = pkg.create_frame_buffer(800, 600)
+    scene = pkg.Scene.create_default()
+    r = pkg.create_renderer(1.5, fb.height, fb.width)
+    msg = r.render(fb, scene)
+    out = capsys.readouterr().out
+    assert "Rendering using patches of size 32, using 450 patches overall" in out
+    assert "Dimensions mismatch" in out
+    assert msg.startswith("Scene rendered in ") and msg.endswith("MP/s)")
+    ref = O.render(O.OracleScene.create_default(), 800, 600, max_depth=3)
+    compare(fb.buffer, ref)
+    fb.normalize()
+    O.normalize(ref)
+    assert float(np.abs(fb.buffer - ref).max()) < TIGHT
+    u8 = fb.to_vec()
+    assert int((u8 != O.to_vec(ref)).sum()) <= 2
+
+
+def test_smoke_entry(entry):
+    entry.smoke()

@@ -1,0 +1,136 @@
+"""Benchmark / test workloads: the five configurations of BASELINE.json, each built
+twice from ONE neutral recipe -- once through the product's host API (-> GPU) and once
+through the oracle's (-> CPU check).  Harness code: used by bench.py, tests/ and
+__graft_entry__.smoke(); not part of the product package.
+
+  C1 demo scene 320x240,  depth 2   (CPU-runnable plumbing case)
+  C2 demo scene 1920x1080, depth 5  (the headline metric's configuration)
+  C3 cornell_box.obj 1920x1080, depth 5 (main.rs:261-327 recipe)
+  C4 demo scene 7680x4320, depth 8
+  C5 256-sphere synthetic 4096x4096, depth 10 (defined HERE; not in the reference)
+"""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CORNELL = os.path.join(GOLDEN, "cornell_box.obj")
+SYNTH_FIXTURE = os.path.join(GOLDEN, "synthetic256.json")
+
+FOV = 1.5   # main.rs:368
+
+CONFIGS = {
+    "C1": dict(scene="demo", width=320, height=240, max_depth=2),
+    "C2": dict(scene="demo", width=1920, height=1080, max_depth=5),
+    "C3": dict(scene="cornell", width=1920, height=1080, max_depth=5),
+    "C4": dict(scene="demo", width=7680, height=4320, max_depth=8),
+    "C5": dict(scene="synthetic256", width=4096, height=4096, max_depth=10),
+}
+
+
+# --------------------------------------------------------------------------
+# C5: seeded synthetic scene.  SplitMix64, seed 0xC0FFEE.
+# --------------------------------------------------------------------------
+def _splitmix64(seed):
+    state = seed & 0xFFFFFFFFFFFFFFFF
+    while True:
+        state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        yield (z >> 11) * (1.0 / 9007199254740992.0)     # uniform [0, 1)
+
+
+def generate_synthetic(n_spheres=256, seed=0xC0FFEE):
+    """Neutral description of the synthetic scene: list of sphere dicts.
+    Draw order per sphere: cx, cy, cz, radius, r, g, b."""
+    u = _splitmix64(seed)
+    spheres = []
+    for i in range(n_spheres):
+        cx = -24. + 48. * next(u)
+        cy = -10. + 24. * next(u)
+        cz = -70. + 58. * next(u)
+        radius = 0.4 + 1.2 * next(u)
+        col = (next(u), next(u), next(u))
+        glass = (i % 4 == 0)
+        spheres.append(dict(center=(cx, cy, cz), radius=radius, color=col, glass=glass))
+    return spheres
+
+
+def load_synthetic():
+    """The frozen fixture (tests/golden/synthetic256.json, written by
+    tests/golden/make_synthetic.py); falls back to regenerating it."""
+    if os.path.exists(SYNTH_FIXTURE):
+        with open(SYNTH_FIXTURE) as f:
+            return json.load(f)["spheres"]
+    return generate_synthetic()
+
+
+def _synthetic_material(sp):
+    # every 4th sphere glass (ri 1.5, reflection 0.3, diffusion 0.2); the others
+    # Reflectance::create_default with exponent 50
+    if sp["glass"]:
+        return dict(diffusion=0.2, diffuse_color=tuple(sp["color"]), specular=1., specular_exponent=50.,
+                    is_glass_like=True, reflection=0.3, refractive_index=1.5)
+    return dict(diffusion=1., diffuse_color=tuple(sp["color"]), specular=1., specular_exponent=50.,
+                is_glass_like=False, reflection=0.95, refractive_index=1.)
+
+
+FLOOR_QUAD = [(20., -3., -50.), (-20., -3., -50.), (-15., -6., -3.), (15., -6., -3.)]   # scene.rs:87-110
+FLOOR_MATERIAL = dict(diffusion=1., diffuse_color=(0.3, 0.9, 0.9), specular=1., specular_exponent=100.,
+                      is_glass_like=True, reflection=0.5, refractive_index=1.5)
+DEMO_LIGHTS = [((0., 0., 0.), (1., 1., 1.), 1.), ((20., 20., 20.), (1., 0.5, 0.5), 0.8)]   # scene.rs:173-200
+
+
+# --------------------------------------------------------------------------
+# builders
+# --------------------------------------------------------------------------
+def product_scene(pkg, name, n_spheres=None):
+    """-> rusty_marcher_amd.Scene for workload scene `name`."""
+    if name == "demo":
+        return pkg.Scene.create_default()
+    if name == "cornell":
+        return pkg.Scene.open_obj(CORNELL)
+    if name == "synthetic256":
+        s = pkg.Scene.new()
+        spheres = load_synthetic()
+        for sp in spheres[:n_spheres]:
+            s.shapes.append(pkg.sphere.create(pkg.Vec3f(*sp["center"]), sp["radius"],
+                                              pkg.Reflectance(**_synthetic_material(sp))))
+        s.shapes.append(pkg.polygon.ConvexPolygon.create([pkg.Vec3f(*p) for p in FLOOR_QUAD],
+                                                         pkg.Reflectance(**FLOOR_MATERIAL)))
+        for pos, col, inten in DEMO_LIGHTS:
+            s.lights.append(pkg.create_light(pkg.Vec3f(*pos), pkg.Vec3f(*col), inten))
+        return s
+    raise KeyError(name)
+
+
+def oracle_scene(O, name, n_spheres=None):
+    """-> oracle.OracleScene for workload scene `name` (independent code path)."""
+    if name == "demo":
+        return O.OracleScene.create_default()
+    if name == "cornell":
+        from oracle import obj_oracle
+        s = O.OracleScene()
+        for _, tris in obj_oracle.load_models(CORNELL):
+            s.add_obj(np.array(tris, dtype=np.float64), (0., 0., -500.))       # main.rs:278-286
+        for pos, col, inten in DEMO_LIGHTS:                                     # main.rs:293-315
+            s.add_light(pos, col, inten)
+        return s
+    if name == "synthetic256":
+        s = O.OracleScene()
+        for sp in load_synthetic()[:n_spheres]:
+            s.add_sphere(sp["center"], sp["radius"], O.reflectance(**_synthetic_material(sp)))
+        s.add_polygon(FLOOR_QUAD, O.reflectance(**FLOOR_MATERIAL))
+        for pos, col, inten in DEMO_LIGHTS:
+            s.add_light(pos, col, inten)
+        return s
+    raise KeyError(name)
+
+
+def patch_rows_for_rank(n_patch_rows, rank, world):
+    """rank r owns patch rows [r*P/N, (r+1)*P/N)."""
+    return (rank * n_patch_rows) // world, ((rank + 1) * n_patch_rows) // world
