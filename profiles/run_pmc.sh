@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collects rocprofv3 PMC counters for bench.py's render kernel, one --pmc pass per
+# counter group (separate runs, kernel-trace only -- never combined with sys traces).
+# usage (on the GPU box, from the repo root):  bash profiles/run_pmc.sh <tag> [bench args]
+set -u
+TAG=${1:-run}; shift || true
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in \
+  "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+  "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT" \
+  "WRITE_SIZE" \
+  "FETCH_SIZE" \
+  "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "rm_render_" not in row["Kernel_Name"]:
+            continue
+        a = agg[row["Counter_Name"]]
+        a[0] += float(row["Counter_Value"]); a[1] += 1
+with open(out + "/summary.csv", "w") as g:
+    g.write("counter,mean_per_launch,launches\n")
+    for k in sorted(agg):
+        g.write("%s,%.1f,%d\n" % (k, agg[k][0] / agg[k][1], agg[k][1]))
+print(open(out + "/summary.csv").read())
+PY

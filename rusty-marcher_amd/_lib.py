@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librusty_marcher_amd.so")
+LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(_HERE, "lib", "librusty_marcher_amd.so")   # RM_LIB_PATH: dev knob for A/B builds
 
 RM_OK = 0
 RM_ERR_INVALID_ARG, RM_ERR_DIMENSIONS, RM_ERR_NO_DEVICE, RM_ERR_HIP = 1, 2, 3, 4

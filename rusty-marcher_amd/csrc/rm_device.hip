@@ -8,156 +8,22 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "rm_internal.h"
-#include "rm_trace.hpp"
+#include "rm_render_kernel.hpp"
 
 using namespace rmdev;
 
+#ifndef RM_WAVES_PER_SIMD
+#define RM_WAVES_PER_SIMD 1
+#endif
 #ifndef RM_BUILD_FLAVOR
 #define RM_BUILD_FLAVOR "strict-fp64"
 #endif
-
-// ---------------------------------------------------------------------------
-// Render kernel
-//
-// One 256-thread workgroup renders one 32x32 patch -- the reference's unit of
-// parallel work (renderer.rs:47,63-89).  The patch is cut into sixteen 8x8
-// tiles; wave w renders tiles w, w+4, w+8, w+12, one lane per pixel, so the 64
-// rays of a wave stay spatially coherent (same primitives hit, same branches).
-// cast_ray's recursion becomes a per-lane depth-first walk of the ray tree with
-// an explicit stack: radiance is linear in the children (renderer.rs:219,249),
-// so each ray carries the product of the reflection factors above it.
-// ---------------------------------------------------------------------------
-
-struct KernelArgs {
-    rm_dev_header H;
-    double half_fov, height, width, ratio;   // Renderer (renderer.rs:17-23)
-    double cam_x, cam_y, cam_z;              // Scene.camera
-    double bg_x, bg_y, bg_z;                 // renderer.rs:40-44
-    uint32_t frame_width;                    // FrameBuffer.width
-    uint32_t patch_row_begin;                // first patch row of the band
-    uint32_t max_depth;                      // renderer.rs:262
-    uint32_t _pad;
-};
-
-struct StackEntry {
-    double ox, oy, oz, dx, dy, dz, w;
-    uint32_t depth, _pad;
-};
-
-extern __shared__ double rm_lds[];
-
-template <int STACK>
-__global__ __launch_bounds__(256) void rm_render_kernel(const double *__restrict__ scene_blob, KernelArgs a,
-                                                         double *__restrict__ frame) {
-    // ---- stage the scene in LDS (every lane then reads it as broadcasts) ----
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(scene_blob);
-        double2 *dst = reinterpret_cast<double2 *>(rm_lds);
-        const uint32_t n2 = a.H.total_words / 2;
-        for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = src[i];
-    }
-    // per-wave 8x8x3 transpose slab for the output stores, behind the scene
-    double *slab = rm_lds + a.H.total_words + (threadIdx.x >> 6) * (64 * 3);
-    __syncthreads();
-
-    SceneView sc;
-    sc.S = rm_lds;
-    sc.H = a.H;
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t px0 = blockIdx.x * 32u;                        // renderer.rs:69
-    const uint32_t py0 = (a.patch_row_begin + blockIdx.y) * 32u;  // renderer.rs:70
-    const V3 cam = mk(a.cam_x, a.cam_y, a.cam_z);
-    const V3 bg = mk(a.bg_x, a.bg_y, a.bg_z);
-
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t tile = k * 4u + wave;
-        const uint32_t tx0 = px0 + (tile & 3u) * 8u;
-        const uint32_t ty0 = py0 + (tile >> 2) * 8u;
-        const uint32_t x = tx0 + (lane & 7u);
-        const uint32_t y = ty0 + (lane >> 3);
-
-        // backproject, renderer.rs:128-135 (no pixel-centre offset)
-        V3 dir = normalized(mk(2. * ((double)x / a.width - 0.5) * a.half_fov * a.ratio,
-                               -2. * ((double)y / a.height - 0.5) * a.half_fov, -1.));
-        V3 orig = cam;
-        double weight = 1.;
-        uint32_t depth = 1;                                       // renderer.rs:83
-        V3 acc = mk(0., 0., 0.);
-
-        StackEntry stack[STACK];
-        int sp = 0;
-
-        for (;;) {
-            Hit h;
-            bool descend = false;
-            if (closest_hit(sc, orig, dir, h)) {
-                const Surface s = surface_at(sc, orig, dir, h);
-                // renderer.rs:272-275: background + direct lighting
-                const V3 L = bg + shade_direct(sc, orig, s);
-                acc = acc + scaled(L, weight);
-                if (s.mat[8] != 0.) {                             // is_glass_like, renderer.rs:277
-                    const double reflection = s.mat[6], ri = s.mat[7];
-                    const V3 incident = dir;
-                    const double w_here = weight;
-                    const uint32_t child_depth = depth + 1u;
-                    // a child beyond the cap returns the background (renderer.rs:262-264)
-                    const bool child_capped = child_depth > a.max_depth;
-                    V3 co, cd;
-                    if (reflect_child(incident, s, ri, co, cd)) { // renderer.rs:195-222
-                        const double cw = w_here * reflection;
-                        if (child_capped) {
-                            acc = acc + scaled(bg, cw);
-                        } else {                                  // pending sibling: at most one per level
-                            StackEntry &e = stack[sp++];
-                            e.ox = co.x; e.oy = co.y; e.oz = co.z;
-                            e.dx = cd.x; e.dy = cd.y; e.dz = cd.z;
-                            e.w = cw; e.depth = child_depth;
-                        }
-                    }
-                    if (refract_child(incident, s, ri, co, cd)) { // renderer.rs:225-252
-                        const double cw = w_here * (1. - reflection);
-                        if (child_capped) {
-                            acc = acc + scaled(bg, cw);
-                        } else {                                  // walk into this child directly
-                            orig = co; dir = cd; weight = cw; depth = child_depth;
-                            descend = true;
-                        }
-                    }
-                }
-            } else if (depth > 1u) {
-                acc = acc + scaled(bg, weight);                   // renderer.rs:302-303
-            }                                                     // primary miss: zero, :305
-            if (descend) continue;
-            if (sp == 0) break;
-            const StackEntry &e = stack[--sp];
-            orig = mk(e.ox, e.oy, e.oz);
-            dir = mk(e.dx, e.dy, e.dz);
-            weight = e.w;
-            depth = e.depth;
-        }
-
-        // ---- store the 8x8 tile: transpose through LDS so that each of the 8 rows
-        // leaves as 192 contiguous bytes in 16-byte pieces (frame.buffer[y][x], :103)
-        slab[lane * 3 + 0] = acc.x;
-        slab[lane * 3 + 1] = acc.y;
-        slab[lane * 3 + 2] = acc.z;
-        __builtin_amdgcn_wave_barrier();
-        const double2 *slab2 = reinterpret_cast<const double2 *>(slab);
-        for (uint32_t q = lane; q < 96u; q += 64u) {
-            const uint32_t row = q / 12u, piece = q % 12u;       // 12 x 16 B per 8-pixel row
-            double2 *dst = reinterpret_cast<double2 *>(frame + ((size_t)(ty0 + row) * a.frame_width + tx0) * 3u);
-            dst[piece] = slab2[row * 12u + piece];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 // With max_depth == 0 the primary ray itself is capped: every pixel is the
 // background (renderer.rs:262-264 with n_recursion = 1 > 0).
@@ -215,8 +81,31 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // Context
 // ---------------------------------------------------------------------------
 
+// How the 8x8 tiles of a band are handed to waves (see rm_render_kernel.hpp): `waves`
+// waves per workgroup, `per_wave` tiles per wave.  Measured at 1080p on the demo scene
+// (profiles/r01_ab_launch_modes.txt): one tile per wave wins (finer units for the
+// hardware dispatcher: 4 tiles per wave 193 us vs 1 tile 122 us); 1 or 4 waves per
+// workgroup differ by ~2 %, so larger scenes share one LDS copy between 4 waves.
+// A persistent variant (waves pulling tiles from a global counter) was measured too and
+// dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
+// RM_KERNEL_MODE="s<waves>x<tiles>" overrides the choice for A/B measurements.
+struct rm_launch_mode {
+    int waves = 0;      // waves per workgroup; 0 = choose from the scene size at launch
+    int per_wave = 1;   // tiles per wave
+};
+
+static bool parse_mode(const char *s, rm_launch_mode *m) {
+    int w = 0, t = 0;
+    if (std::sscanf(s, "s%dx%d", &w, &t) == 2) { m->waves = w; m->per_wave = t; return true; }
+    return false;
+}
+
+// dispatch order of the tiles (tile_origin): RM_TILE_ORDER = natural | reverse | hash
+enum { TILE_ORDER_NATURAL = 0, TILE_ORDER_REVERSE = 1, TILE_ORDER_HASH = 2 };
+
 struct rm_ctx {
     int device = -1;
+    rm_launch_mode mode;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string error;
@@ -228,6 +117,14 @@ struct rm_ctx {
     double *d_scene = nullptr;
     size_t d_scene_words = 0;
     rm_vec3 camera{0., 0., 0.};
+    bool integer_exponents = false;   // every material's specular_exponent is a small non-negative integer
+    bool force_generic_pow = false;   // RM_FORCE_GENERIC_POW=1 (A/B knob)
+    // Bottom-up by default: workgroups are dispatched in id order and the drain at the end
+    // of a launch runs at low occupancy, so the rows that are expensive in the
+    // reference's scenes (ground, objects resting on it) go first and the cheap sky rows
+    // drain (1080p demo: 124 -> 116 us; hashed order 131 us).
+    int tile_order = TILE_ORDER_REVERSE;
+    bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
 
     // device framebuffer of rm_render
     double *d_frame = nullptr;
@@ -255,8 +152,18 @@ static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
 
 // Scene blob + output slabs must fit beside at least one other workgroup.
 static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 64 * 1024;
-static constexpr size_t RM_LDS_SLAB_BYTES = 4 * 64 * 3 * sizeof(double);
 
+// Kernel instantiation table: stack depth x pow flavour for one launch geometry.
+template <int W, int T>
+static const void *pick_static(int stack, int pow_mode) {
+#define RM_ROW(S)                                                               \
+    if (stack == S)                                                             \
+        return pow_mode == POW_INTEGER ? (const void *)rm_render_static<S, POW_INTEGER, W, T> \
+                                       : (const void *)rm_render_static<S, POW_GENERIC, W, T>;
+    RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
+#undef RM_ROW
+    return nullptr;
+}
 extern "C" {
 
 const char *rm_build_info(void) {
@@ -297,6 +204,18 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc(&ctx->d_max, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if (const char *env = std::getenv("RM_FORCE_GENERIC_POW")) ctx->force_generic_pow = env[0] == '1';
+    if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
+    if (const char *env = std::getenv("RM_TILE_ORDER"))
+        ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
+                        : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
+    if (const char *env = std::getenv("RM_KERNEL_MODE")) {
+        if (!parse_mode(env, &ctx->mode)) {
+            rm_set_host_error(std::string("rm_init: cannot parse RM_KERNEL_MODE=") + env);
+            rm_destroy(ctx);
+            return RM_ERR_INVALID_ARG;
+        }
+    }
     *out = ctx;
     return RM_OK;
 }
@@ -463,6 +382,13 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     ctx->H = H;
     ctx->camera = d->camera;
     ctx->have_scene = true;
+    // specular_pow<POW_INTEGER> applies when pow(x, y) is a plain integer power for every material
+    bool int_exp = true;
+    for (uint32_t q = 0; q < H.n_prims; q++) {
+        const double y = blob[H.off_materials + RM_MATERIAL_WORDS * q + 5];
+        int_exp = int_exp && (y >= 0. && y <= 1048576. && y == std::floor(y));
+    }
+    ctx->integer_exponents = int_exp;
     return RM_OK;
 }
 
@@ -513,19 +439,59 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     a.frame_width = p->frame_width;
     a.patch_row_begin = row_begin;
     a.max_depth = p->max_depth;
-    const size_t lds = (size_t)ctx->H.total_words * sizeof(double) + RM_LDS_SLAB_BYTES;
-    const dim3 grid(n_width, row_end - row_begin), block(256);
+    a.n_width = n_width;
+    a.n_tiles = (row_end - row_begin) * n_width * 16u;
+    a.debug_stamps = nullptr;
+    // dispatch order: tile = (id * order_mul + order_add) % n_tiles, a bijection
+    a.order_mul = 1; a.order_add = 0;
+    if (ctx->tile_order == TILE_ORDER_REVERSE && a.n_tiles > 1) {             // id -> n-1-id
+        a.order_mul = a.n_tiles - 1; a.order_add = a.n_tiles - 1;
+    } else if (ctx->tile_order == TILE_ORDER_HASH && a.n_tiles > 2) {
+        uint32_t mul = (uint32_t)(a.n_tiles * 0.6180339887) | 1u;
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { uint32_t t = x % y; x = y; y = t; } return x; };
+        while (gcd(mul, a.n_tiles) != 1) mul += 2;
+        a.order_mul = mul % a.n_tiles;
+    }
+
+    // launch geometry: one tile per wave; small scenes get one wave per workgroup,
+    // larger ones share the LDS copy of the scene between four waves
+    rm_launch_mode m = ctx->mode;
+    if (m.waves == 0) { m.waves = (size_t)ctx->H.total_words * sizeof(double) <= 4096 ? 1 : 4; m.per_wave = 1; }
+    const size_t lds = (size_t)ctx->H.total_words * sizeof(double) + (size_t)m.waves * 64 * 3 * sizeof(double);
+    const dim3 block(m.waves * 64);
+
     // The walk descends into the refracted child directly and parks the reflected one:
     // at most one pending sibling per level below the cap, i.e. max_depth - 1 entries.
-    if (p->max_depth <= 5)
-        hipLaunchKernelGGL(rm_render_kernel<4>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
-    else if (p->max_depth <= 9)
-        hipLaunchKernelGGL(rm_render_kernel<8>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
-    else if (p->max_depth <= 17)
-        hipLaunchKernelGGL(rm_render_kernel<16>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
-    else
-        hipLaunchKernelGGL(rm_render_kernel<32>, grid, block, lds, stream, ctx->d_scene, a, d_frame);
-    RM_HIP(ctx, hipGetLastError());
+    const int stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
+    const int pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
+
+    const void *fn = nullptr;
+    if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode);
+    else if (m.waves == 4 && m.per_wave == 1) fn = pick_static<4, 1>(stack, pow_mode);
+    else if (m.waves == 1 && m.per_wave == 4) fn = pick_static<1, 4>(stack, pow_mode);
+    else if (m.waves == 4 && m.per_wave == 4) fn = pick_static<4, 4>(stack, pow_mode);
+    else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE");
+    const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
+    const dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
+    if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging
+#ifdef RM_EXP_STAMPS
+    unsigned long long *d_stamps = nullptr;
+    const size_t n_waves = (size_t)grid.x * m.waves;
+    RM_HIP(ctx, hipMalloc(&d_stamps, n_waves * 32));
+    RM_HIP(ctx, hipMemset(d_stamps, 0, n_waves * 32));
+    a.debug_stamps = d_stamps;
+#endif
+    void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
+    RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
+#ifdef RM_EXP_STAMPS
+    RM_HIP(ctx, hipStreamSynchronize(stream));
+    if (const char *path = std::getenv("RM_DEBUG_STAMPS")) {
+        std::vector<unsigned long long> h(n_waves * 4);
+        RM_HIP(ctx, hipMemcpy(h.data(), d_stamps, n_waves * 32, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    }
+    RM_HIP(ctx, hipFree(d_stamps));
+#endif
     return RM_OK;
 }
 

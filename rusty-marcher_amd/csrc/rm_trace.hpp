@@ -47,6 +47,7 @@ __device__ __forceinline__ V3 normalized(V3 a) {
 // Scene view: S points at the blob (LDS copy), H carries counts and offsets in SGPRs.
 struct SceneView {
     const double *S;
+    const double *__restrict__ G;
     rm_dev_header H;
 };
 
@@ -72,7 +73,7 @@ struct Hit {
 
 // ---- closest hit ---------------------------------------------------------
 __device__ __forceinline__ bool closest_hit(const SceneView &sc, V3 o, V3 d, Hit &out) {
-    const double *S = sc.S;
+    const double *__restrict__ S = sc.G;
     bool hit = false;
     double best = 0., best_t = 0.;
     uint32_t best_pid = 0;
@@ -159,7 +160,7 @@ __device__ __forceinline__ bool closest_hit(const SceneView &sc, V3 o, V3 d, Hit
 // has found an occluder keeps walking with its result latched; the wave leaves
 // a loop early once every active lane is occluded.
 __device__ __forceinline__ bool any_hit(const SceneView &sc, V3 o, V3 d) {
-    const double *S = sc.S;
+    const double *__restrict__ S = sc.G;
     bool occ = false;
 
     for (uint32_t i = 0; i < sc.H.n_spheres; i++) {
@@ -259,9 +260,33 @@ __device__ __forceinline__ V3 reflect(V3 incident, V3 normal) {
     return incident - scaled(normal, 2. * dot(incident, normal));
 }
 
+// ---- specular power: f64::powf (renderer.rs:186-188) ---------------------------------
+// POW_GENERIC: the device libm pow (<= 1 ulp), any exponent.  Its ~40 polynomial
+// constants cannot be f64 literals on gfx950, so the compiler parks them in VGPRs for
+// the whole kernel (+38 VGPRs, one wave per SIMD less).
+// POW_INTEGER: exponent is a non-negative integer (checked for every material at
+// scene upload): binary powering, bit-for-bit the same special cases as pow for such
+// exponents (x^0 = 1 also for NaN; 0^n = 0; sign of negative bases), <= ~10 roundings
+// instead of 1, no constants.
+enum { POW_GENERIC = 0, POW_INTEGER = 1 };
+
+template <int POW>
+__device__ __forceinline__ double specular_pow(double x, double y) {
+    if (POW == POW_GENERIC) return pow(x, y);
+    uint32_t n = (uint32_t)y;
+    double r = 1., b = x;
+    while (__any(n != 0u)) {
+        if (n & 1u) r = r * b;
+        b = b * b;
+        n >>= 1;
+    }
+    return r;
+}
+
 // ---- direct lighting: renderer.rs:153-193 ---------------------------------------
 // `origin` is the origin of the ray that produced the hit (renderer.rs:275), so
 // for secondary rays the "viewer" is the previous hit point.
+template <int POW>
 __device__ __forceinline__ V3 shade_direct(const SceneView &sc, V3 origin, const Surface &s) {
     const double *m = s.mat;
     const V3 diffuse_color = mk(m[1], m[2], m[3]);
@@ -269,7 +294,7 @@ __device__ __forceinline__ V3 shade_direct(const SceneView &sc, V3 origin, const
     const V3 dir_to_viewer = normalized(origin - s.point);            // renderer.rs:149
     V3 li = mk(0., 0., 0.);
     for (uint32_t l = 0; l < sc.H.n_lights; l++) {
-        const double *lt = sc.S + sc.H.off_lights + RM_LIGHT_WORDS * l;
+        const double *lt = sc.G + sc.H.off_lights + RM_LIGHT_WORDS * l;
         const V3 lpos = mk(lt[0], lt[1], lt[2]);
         const V3 lcol = mk(lt[3], lt[4], lt[5]);
         const double intensity = lt[6];
@@ -282,7 +307,7 @@ __device__ __forceinline__ V3 shade_direct(const SceneView &sc, V3 origin, const
         li = li + scaled(scaled(lcol * diffuse_color, diffusion), intensity);   // :181-183
         const V3 reflected = reflect(neg(light_dir), s.normal);       // :144-145
         const double sf = __builtin_fmax(dot(reflected, dir_to_viewer), 0.);    // :150
-        const double spec = pow(sf * specular_k, exponent);           // :186-188
+        const double spec = specular_pow<POW>(sf * specular_k, exponent);   // :186-188
         li = li + scaled(lcol, spec);                                 // :189
     }
     return scaled(li, m[0]);                                          // :192

@@ -164,6 +164,26 @@ def test_deep_recursion_needs_the_stack(pkg, O, ctx):
     assert not np.array_equal(refs[5], refs[10])
 
 
+@pytest.mark.parametrize("exponents", [(30., 100., 1.), (0., 2., 1000.), (12.5, 30., 7.), (0.5, 1.5, 99.9)])
+def test_specular_exponent_flavours(pkg, O, ctx, exponents):
+    """renderer.rs:186-188 `powf`: integer-valued exponents take the kernel's binary
+    powering flavour, anything else the device pow -- both against the oracle's libm pow."""
+    def build(add_sphere, add_light):
+        for k, e in enumerate(exponents):
+            add_sphere((-6. + 6. * k, 0.5 * k, -14.), 2.6,
+                       dict(diffusion=0.8, diffuse_color=(0.2 + 0.3 * k, 0.5, 0.9 - 0.3 * k), specular=0.9,
+                            specular_exponent=e, is_glass_like=(k == 1), reflection=0.3, refractive_index=1.4))
+        add_light((0., 0., 0.), (1., 1., 1.), 1.)
+        add_light((10., 15., 5.), (1., 0.8, 0.6), 0.7)
+
+    s, so = pkg.Scene.new(), O.OracleScene()
+    build(lambda c, r, m: s.shapes.append(pkg.sphere.create(pkg.Vec3f(*c), r, pkg.Reflectance(**m))),
+          lambda p, c, i: s.lights.append(pkg.create_light(pkg.Vec3f(*p), pkg.Vec3f(*c), i)))
+    build(lambda c, r, m: so.add_sphere(c, r, O.reflectance(**m)), lambda p, c, i: so.add_light(p, c, i))
+    gpu, _ = gpu_render(pkg, ctx, s, 320, 160, 4)
+    compare(gpu, O.render(so, 320, 160, max_depth=4))
+
+
 # ---------------------------------------------------------------- edge cases
 def test_bottom_rows_keep_previous_contents(pkg, O, ctx):
     """renderer.rs:53: H % 32 bottom rows are never written -- stale pixels survive."""
