@@ -115,24 +115,8 @@ def main():
     frame_ptr = C.c_void_p(frame.data_ptr())
     stream_ptr = C.c_void_p(stream.cuda_stream)
 
-    bands = [workloads.patch_rows_for_rank(n_rows, r, world) for r in range(world)]
-
     def gather():
-        """One collective at frame end: every peer sends its band straight into rank 0's
-        framebuffer (unequal bands -> grouped send/recv)."""
-        ops = []
-        if rank == 0:
-            for r in range(1, world):
-                b, e = bands[r]
-                if e > b:
-                    ops.append(dist.P2POp(dist.irecv, frame[b * 32:e * 32], r))
-        else:
-            b, e = bands[rank]
-            if e > b:
-                ops.append(dist.P2POp(dist.isend, frame[b * 32:e * 32], 0))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()      # stream-ordered on the current stream; does not block the host
+        workloads.gather_bands(dist, frame, n_rows, rank, world)
 
     def step(ev=None):
         if ev is not None:

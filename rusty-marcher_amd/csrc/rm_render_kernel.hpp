@@ -19,6 +19,15 @@
 
 namespace rmdev {
 
+// Tile shape (pixels).  RM_TILE_W x (64 / RM_TILE_W): 16x4 makes every tile row 384
+// bytes = three whole 128-byte lines owned by one wave (8x8 rows are 192 bytes and
+// share lines between waves: measured HBM write traffic 1.84x the frame's bytes).
+#ifndef RM_TILE_W
+#define RM_TILE_W 16
+#endif
+constexpr uint32_t TILE_W = RM_TILE_W, TILE_H = 64u / RM_TILE_W;
+static_assert(TILE_W == 8 || TILE_W == 16 || TILE_W == 32, "tile width");
+
 struct KernelArgs {
     rm_dev_header H;
     double half_fov, height, width, ratio;   // Renderer (renderer.rs:17-23)
@@ -60,16 +69,16 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, ui
     const uint32_t tile = (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
     const uint32_t patch = tile >> 4, sub = tile & 15u;
     const uint32_t pcol = patch % a.n_width, prow = patch / a.n_width;
-    tx0 = pcol * 32u + (sub & 3u) * 8u;
-    ty0 = (a.patch_row_begin + prow) * 32u + (sub >> 2) * 8u;
+    tx0 = pcol * 32u + (sub & (32u / TILE_W - 1u)) * TILE_W;
+    ty0 = (a.patch_row_begin + prow) * 32u + (sub / (32u / TILE_W)) * TILE_H;
 }
 
 template <int STACK, int POW>
 __device__ __forceinline__ void render_tile(const SceneView &sc, const KernelArgs &a, uint32_t tx0, uint32_t ty0,
                                             double *slab, double *__restrict__ frame) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t x = tx0 + (lane & 7u);
-    const uint32_t y = ty0 + (lane >> 3);
+    const uint32_t x = tx0 + (lane % TILE_W);
+    const uint32_t y = ty0 + (lane / TILE_W);
     const V3 bg = mk(a.bg_x, a.bg_y, a.bg_z);
 
     // backproject, renderer.rs:128-135 (no pixel-centre offset)
@@ -139,10 +148,11 @@ __device__ __forceinline__ void render_tile(const SceneView &sc, const KernelArg
     slab[lane * 3 + 2] = acc.z;
     __builtin_amdgcn_wave_barrier();
     const double2 *slab2 = reinterpret_cast<const double2 *>(slab);
+    constexpr uint32_t PIECES = TILE_W * 3u / 2u;             // 16-byte pieces per tile row
     for (uint32_t q = lane; q < 96u; q += 64u) {
-        const uint32_t row = q / 12u, piece = q % 12u;       // 12 x 16 B per 8-pixel row
+        const uint32_t row = q / PIECES, piece = q % PIECES;
         double2 *dst = reinterpret_cast<double2 *>(frame + ((size_t)(ty0 + row) * a.frame_width + tx0) * 3u);
-        dst[piece] = slab2[row * 12u + piece];
+        dst[piece] = slab2[row * PIECES + piece];
     }
     __builtin_amdgcn_wave_barrier();
 }

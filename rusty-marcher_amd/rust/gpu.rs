@@ -1,0 +1,258 @@
+//! engine/src/gpu.rs -- Rust side of the MI355X backend (drop-in for the Rayon patch
+//! loop of renderer.rs:63-108).  UNVERIFIED: written against include/rusty_marcher_amd.h,
+//! not compiled -- the build image has no rustc/cargo.
+//!
+//! Edition 2015 like the rest of the crate (bare `use geometry::..` paths).
+//! Link with:  cargo:rustc-link-lib=dylib=rusty_marcher_amd  (build.rs)
+
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+use std::ptr;
+
+use framebuffer::FrameBuffer;
+use geometry::Vec3f;
+use shapes::Reflectance;
+
+// ---- mirrors of the C structs (include/rusty_marcher_amd.h) -------------------------
+
+#[repr(C)]
+#[derive(Copy, Clone)]
+pub struct RmVec3 {
+    pub x: f64,
+    pub y: f64,
+    pub z: f64,
+}
+
+impl From<Vec3f> for RmVec3 {
+    fn from(v: Vec3f) -> RmVec3 {
+        RmVec3 { x: v.x, y: v.y, z: v.z }
+    }
+}
+
+#[repr(C)]
+#[derive(Copy, Clone)]
+pub struct RmReflectance {
+    pub diffusion: f64,
+    pub diffuse_color: RmVec3,
+    pub specular: f64,
+    pub specular_exponent: f64,
+    pub is_glass_like: i32,
+    pub _pad: i32,
+    pub reflection: f64,
+    pub refractive_index: f64,
+}
+
+impl From<Reflectance> for RmReflectance {
+    fn from(r: Reflectance) -> RmReflectance {
+        RmReflectance {
+            diffusion: r.diffusion,
+            diffuse_color: r.diffuse_color.into(),
+            specular: r.specular,
+            specular_exponent: r.specular_exponent,
+            is_glass_like: r.is_glass_like as i32,
+            _pad: 0,
+            reflection: r.reflection,
+            refractive_index: r.refractive_index,
+        }
+    }
+}
+
+#[repr(C)]
+pub struct RmSceneDesc {
+    pub shapes: *const c_void,
+    pub n_shapes: u32,
+    pub spheres: *const c_void,
+    pub n_spheres: u32,
+    pub polygons: *const c_void,
+    pub n_polygons: u32,
+    pub polygon_vertices: *const RmVec3,
+    pub n_polygon_vertices: u32,
+    pub triangles: *const c_void,
+    pub n_triangles: u32,
+    pub lights: *const c_void,
+    pub n_lights: u32,
+    pub camera: RmVec3,
+}
+
+#[repr(C)]
+pub struct RmParams {
+    pub fov: f64,
+    pub half_fov: f64,
+    pub height: f64,
+    pub width: f64,
+    pub ratio: f64,
+    pub frame_width: u32,
+    pub frame_height: u32,
+    pub max_depth: u32,
+    pub patch_size: u32,
+    pub background: RmVec3,
+    pub patch_row_begin: u32,
+    pub patch_row_end: u32,
+    pub flags: u32,
+    pub _pad: u32,
+}
+
+#[repr(C)]
+#[derive(Default)]
+pub struct RmTiming {
+    pub kernel_ms: f64,
+    pub d2h_ms: f64,
+    pub total_ms: f64,
+}
+
+pub enum RmScene {}
+pub enum RmCtx {}
+
+#[link(name = "rusty_marcher_amd")]
+extern "C" {
+    fn rm_create_renderer(fov: f64, height: f64, width: f64, out: *mut RmParams);
+    fn rm_scene_new(out: *mut *mut RmScene) -> c_int;
+    fn rm_scene_free(scene: *mut RmScene);
+    fn rm_scene_add_sphere(s: *mut RmScene, c: RmVec3, radius: f64, r: *const RmReflectance) -> c_int;
+    fn rm_scene_add_polygon(s: *mut RmScene, v: *const RmVec3, n: u32, r: *const RmReflectance) -> c_int;
+    fn rm_scene_add_mesh(s: *mut RmScene, tri_xyz: *const f64, n_triangles: u32, offset: RmVec3) -> c_int;
+    fn rm_scene_offset_shape(s: *mut RmScene, shape_index: u32, offset: RmVec3) -> c_int;
+    fn rm_scene_add_light(s: *mut RmScene, position: RmVec3, color: RmVec3, intensity: f64) -> c_int;
+    fn rm_scene_set_camera(s: *mut RmScene, camera: RmVec3) -> c_int;
+    fn rm_scene_get_desc(s: *const RmScene, out: *mut RmSceneDesc) -> c_int;
+    fn rm_format_status(buf: *mut c_char, buflen: usize, ms: u64, w: u32, h: u32) -> c_int;
+    fn rm_init(device_ordinal: c_int, out: *mut *mut RmCtx) -> c_int;
+    fn rm_destroy(ctx: *mut RmCtx);
+    fn rm_last_error(ctx: *const RmCtx) -> *const c_char;
+    fn rm_scene_upload(ctx: *mut RmCtx, desc: *const RmSceneDesc) -> c_int;
+    fn rm_render(ctx: *mut RmCtx, p: *const RmParams, host_rgb: *mut f64, t: *mut RmTiming) -> c_int;
+}
+
+/// The reference's failure mode on this path is a panic.
+fn check(status: c_int, ctx: *const RmCtx) {
+    if status != 0 {
+        let msg = unsafe { CStr::from_ptr(rm_last_error(ctx)) }.to_string_lossy().into_owned();
+        panic!("rusty_marcher_amd: status {}: {}", status, msg);
+    }
+}
+
+/// What `trait Shape` lacks for a GPU backend: a way to hand over the primitive's
+/// parameters (sphere.rs:6-11 and polygon.rs:6-12 keep their fields private).
+/// Each implementor adds itself to the flat scene; see INTEGRATION.md for the three
+/// five-line impls.
+pub struct SceneSink {
+    scene: *mut RmScene,
+}
+
+impl SceneSink {
+    pub fn sphere(&mut self, center: Vec3f, radius: f64, r: Reflectance) {
+        let rr: RmReflectance = r.into();
+        check(unsafe { rm_scene_add_sphere(self.scene, center.into(), radius, &rr) }, ptr::null());
+    }
+    pub fn polygon(&mut self, vertices: &[Vec3f], r: Reflectance) {
+        let v: Vec<RmVec3> = vertices.iter().map(|p| (*p).into()).collect();
+        let rr: RmReflectance = r.into();
+        check(unsafe { rm_scene_add_polygon(self.scene, v.as_ptr(), v.len() as u32, &rr) }, ptr::null());
+    }
+    /// One `Obj`: triangles as 9 f64 each (already offset: pass Vec3f::zero()), or the
+    /// un-offset vertices plus the offsets applied so far through `offset_last`.
+    pub fn mesh(&mut self, tri_xyz: &[f64], offset: Vec3f) {
+        check(
+            unsafe { rm_scene_add_mesh(self.scene, tri_xyz.as_ptr(), (tri_xyz.len() / 9) as u32, offset.into()) },
+            ptr::null(),
+        );
+    }
+    pub fn offset_shape(&mut self, index: u32, off: Vec3f) {
+        check(unsafe { rm_scene_offset_shape(self.scene, index, off.into()) }, ptr::null());
+    }
+}
+
+/// One GPU: context + reusable staging buffer.  Owned by `Renderer` (renderer.rs:17-23
+/// gains a `gpu: RefCell<Gpu>` field) or by `Win`.
+pub struct Gpu {
+    ctx: *mut RmCtx,
+    staging: Vec<f64>,
+}
+
+impl Gpu {
+    pub fn new(device: i32) -> Gpu {
+        let mut ctx: *mut RmCtx = ptr::null_mut();
+        check(unsafe { rm_init(device, &mut ctx) }, ptr::null());
+        Gpu { ctx, staging: Vec::new() }
+    }
+
+    /// Body of `Renderer::render` (renderer.rs:36-126) with the Rayon loop and the
+    /// serial scatter replaced by one library call.
+    pub fn render(
+        &mut self,
+        fov: f64,
+        height: f64,
+        width: f64,
+        frame: &mut FrameBuffer,
+        scene: &::scene::Scene,
+    ) -> String {
+        let now = ::std::time::Instant::now();
+        if (frame.height % 32 != 0) || (frame.width % 32 != 0) {
+            println!("Dimensions mismatch") // renderer.rs:49-51
+        }
+
+        // flatten Scene -> rm_scene (shapes in list order: ties, shapes.rs:130)
+        let mut raw: *mut RmScene = ptr::null_mut();
+        check(unsafe { rm_scene_new(&mut raw) }, ptr::null());
+        {
+            let mut sink = SceneSink { scene: raw };
+            for shape in &scene.shapes {
+                shape.describe(&mut sink); // the added trait method
+            }
+        }
+        for l in &scene.lights {
+            // colours are already L-inf normalised (lights.rs:10-16); normalising again is a no-op
+            check(unsafe { rm_scene_add_light(raw, l.position.into(), l.color.into(), l.intensity) }, ptr::null());
+        }
+        check(unsafe { rm_scene_set_camera(raw, scene.camera.into()) }, ptr::null());
+        let mut desc: RmSceneDesc = unsafe { ::std::mem::zeroed() };
+        check(unsafe { rm_scene_get_desc(raw, &mut desc) }, ptr::null());
+        check(unsafe { rm_scene_upload(self.ctx, &desc) }, self.ctx);
+        unsafe { rm_scene_free(raw) };
+
+        let mut p: RmParams = unsafe { ::std::mem::zeroed() };
+        unsafe { rm_create_renderer(fov, height, width, &mut p) };
+        p.frame_width = frame.width as u32; // renderer.rs:53-54 read the FrameBuffer, not the Renderer
+        p.frame_height = frame.height as u32;
+        p.max_depth = 3; // renderer.rs:262
+
+        // FrameBuffer.buffer is Vec<Vec<Vec3f>>: one allocation per row (framebuffer.rs:12-22),
+        // and Vec3f is not #[repr(C)].  Render into a flat staging buffer that first
+        // receives the current contents (rows below the last whole patch row must keep
+        // them, renderer.rs:53), then copy back.
+        let n = frame.width * frame.height * 3;
+        self.staging.resize(n, 0.);
+        for (j, row) in frame.buffer.iter().enumerate() {
+            for (i, px) in row.iter().enumerate() {
+                let k = (j * frame.width + i) * 3;
+                self.staging[k] = px.x;
+                self.staging[k + 1] = px.y;
+                self.staging[k + 2] = px.z;
+            }
+        }
+        let mut timing = RmTiming::default();
+        check(unsafe { rm_render(self.ctx, &p, self.staging.as_mut_ptr(), &mut timing) }, self.ctx);
+        for (j, row) in frame.buffer.iter_mut().enumerate() {
+            for (i, px) in row.iter_mut().enumerate() {
+                let k = (j * frame.width + i) * 3;
+                px.x = self.staging[k];
+                px.y = self.staging[k + 1];
+                px.z = self.staging[k + 2];
+            }
+        }
+
+        // renderer.rs:111-125
+        let ms = now.elapsed().as_secs() * 1_000 + u64::from(now.elapsed().subsec_nanos()) / 1_000_000;
+        let mut buf = [0 as c_char; 256];
+        unsafe { rm_format_status(buf.as_mut_ptr(), buf.len(), ms, frame.width as u32, frame.height as u32) };
+        let message = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
+        println!("{}", message);
+        message
+    }
+}
+
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        unsafe { rm_destroy(self.ctx) }
+    }
+}

@@ -1,0 +1,69 @@
+"""N > 1 plumbing on CPU (gloo): row-band ownership + the single gather of bench.py
+(workloads.gather_bands).  The bands are rendered by the oracle here -- the GPU kernel's
+own band rendering is covered by test_gpu_parity.test_bands_tile_the_frame_bitwise."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, w, h, depth, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    import workloads
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        O = G.load_oracle()
+        n_rows = h // 32
+        band = workloads.patch_rows_for_rank(n_rows, rank, world)
+        frame = np.full((h, w, 3), -1.0)                       # sentinel: untouched rows stay -1
+        if band[1] > band[0]:
+            O.render(O.OracleScene.create_default(), w, h, max_depth=depth, n_threads=2, frame=frame, band=band)
+        t = torch.from_numpy(frame)
+        workloads.gather_bands(dist, t, n_rows, rank, world)
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, t.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 128, 100), (3, 96, 128), (2, 64, 40)])
+def test_band_gather_reassembles_the_frame(O, tmp_path, world, w, h):
+    import torch.multiprocessing as mp
+    depth = 3
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, depth, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = np.full((h, w, 3), -1.0)
+    O.render(O.OracleScene.create_default(), w, h, max_depth=depth, frame=ref)
+    assert np.array_equal(got, ref)
+    assert np.all(got[h - h % 32:] == -1.0) or h % 32 == 0     # rows below the last patch row untouched
+
+
+def test_band_partition_properties():
+    sys.path.insert(0, ROOT)
+    import workloads
+    for n_rows in (0, 1, 7, 33, 128, 135):
+        for world in (1, 2, 3, 4, 8):
+            bands = [workloads.patch_rows_for_rank(n_rows, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == n_rows
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in bands]
+            assert max(sizes) - min(sizes) <= 1
+    # 8K has 135 patch rows -> 16 or 17 per rank on 8 GPUs
+    assert sorted(set(e - b for b, e in (workloads.patch_rows_for_rank(135, r, 8) for r in range(8)))) == [16, 17]

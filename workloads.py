@@ -134,3 +134,26 @@ def oracle_scene(O, name, n_spheres=None):
 def patch_rows_for_rank(n_patch_rows, rank, world):
     """rank r owns patch rows [r*P/N, (r+1)*P/N)."""
     return (rank * n_patch_rows) // world, ((rank + 1) * n_patch_rows) // world
+
+
+def gather_bands(dist, frame, n_patch_rows, rank, world, dst=0):
+    """The one collective of a row-sharded frame: every peer sends its band
+    of `frame` ([H][W][3] tensor, full-frame layout on every rank) straight into the same
+    rows of rank `dst`'s frame.  Bands may be unequal or empty, hence grouped send/recv
+    rather than an all-gather.  Returns the list of requests already waited on."""
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            if r == dst:
+                continue
+            b, e = patch_rows_for_rank(n_patch_rows, r, world)
+            if e > b:
+                ops.append(dist.P2POp(dist.irecv, frame[b * 32:e * 32], r))
+    else:
+        b, e = patch_rows_for_rank(n_patch_rows, rank, world)
+        if e > b:
+            ops.append(dist.P2POp(dist.isend, frame[b * 32:e * 32], dst))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    for req in reqs:
+        req.wait()          # on CUDA streams this orders the stream, it does not block the host
+    return reqs
