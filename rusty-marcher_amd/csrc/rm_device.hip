@@ -304,7 +304,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     auto take = [&](uint32_t words) { uint32_t o = off; off += (words + 1u) & ~1u; return o; };
     H.off_spheres = take(H.n_spheres * RM_SPHERE_WORDS);
     H.off_polygons = take(H.n_polygons * RM_POLYGON_WORDS);
-    H.off_pverts = take(n_pverts * RM_PVERT_WORDS);
+    H.off_pverts = take((n_pverts + 1u) * RM_PVERT_WORDS);   // +1: the loops fetch four vertices at a time
     H.off_triangles = take(H.n_triangles * RM_TRIANGLE_WORDS);
     H.off_materials = take(H.n_prims * RM_MATERIAL_WORDS);
     H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
@@ -474,7 +474,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
     const dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
     if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging
-#ifdef RM_EXP_STAMPS
+#if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     unsigned long long *d_stamps = nullptr;
     const size_t n_waves = (size_t)grid.x * m.waves;
     RM_HIP(ctx, hipMalloc(&d_stamps, n_waves * 32));
@@ -483,7 +483,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
 #endif
     void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
-#ifdef RM_EXP_STAMPS
+#if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     RM_HIP(ctx, hipStreamSynchronize(stream));
     if (const char *path = std::getenv("RM_DEBUG_STAMPS")) {
         std::vector<unsigned long long> h(n_waves * 4);

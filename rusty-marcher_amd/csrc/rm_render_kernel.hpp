@@ -92,13 +92,23 @@ __device__ __forceinline__ void render_tile(const SceneView &sc, const KernelArg
     StackEntry stack[STACK];
     int sp = 0;
 
+#ifdef RM_EXP_PHASES   // diagnostic build: shader-clock cycles per phase, summed per wave
+    unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_closest = 0, ph_shade = 0, ph_child = 0, ph_setup = 0;
+#define RM_PHASE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n__ = __builtin_amdgcn_s_memtime(); acc += n__ - ph_t; ph_t = n__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RM_PHASE(acc) do {} while (0)
+#endif
+    RM_PHASE(ph_setup);
     for (;;) {
         Hit h;
         bool descend = false;
-        if (closest_hit(sc, orig, dir, h)) {
+        const bool got = closest_hit(sc, orig, dir, h);
+        RM_PHASE(ph_closest);
+        if (got) {
             const Surface s = surface_at(sc, orig, dir, h);
             // renderer.rs:272-275: background + direct lighting
             const V3 L = bg + shade_direct<POW>(sc, orig, s);
+            RM_PHASE(ph_shade);
             acc = acc + scaled(L, weight);
             if (s.mat[8] != 0.) {                             // is_glass_like, renderer.rs:277
                 const double reflection = s.mat[6], ri = s.mat[7];
@@ -132,6 +142,7 @@ __device__ __forceinline__ void render_tile(const SceneView &sc, const KernelArg
         } else if (depth > 1u) {
             acc = acc + scaled(bg, weight);                   // renderer.rs:302-303
         }                                                     // primary miss: zero, :305
+        RM_PHASE(ph_child);
         if (descend) continue;
         if (sp == 0) break;
         const StackEntry &e = stack[--sp];
@@ -155,6 +166,13 @@ __device__ __forceinline__ void render_tile(const SceneView &sc, const KernelArg
         dst[piece] = slab2[row * PIECES + piece];
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef RM_EXP_PHASES
+    RM_PHASE(ph_setup);
+    if (lane == 0 && a.debug_stamps) {
+        unsigned long long *o = a.debug_stamps + 4ull * blockIdx.x;
+        o[0] = ph_closest; o[1] = ph_shade; o[2] = ph_child; o[3] = ph_setup;
+    }
+#endif
 }
 
 // ---- static mode ---------------------------------------------------------------

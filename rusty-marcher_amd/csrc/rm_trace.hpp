@@ -71,162 +71,235 @@ struct Hit {
     uint32_t pid;   // device primitive id
 };
 
-// ---- closest hit ---------------------------------------------------------
-__device__ __forceinline__ bool closest_hit(const SceneView &sc, V3 o, V3 d, Hit &out) {
-    const double *__restrict__ S = sc.G;
-    bool hit = false;
-    double best = 0., best_t = 0.;
-    uint32_t best_pid = 0;
+// ---- primitive records as the loops read them ------------------------------------
+// The loops below are wave-uniform: the records are fetched with scalar loads into
+// SGPRs and feed the FP64 ops as scalar operands.  A scalar load costs a full round
+// trip to the scalar cache per dependent use, so records are fetched in BATCHES -- four
+// spheres, a polygon header together with its first four vertices, two triangles --
+// and one wait covers the whole batch.
+struct SphereRec { double cx, cy, cz, r2; };
+struct PolyRec { double nx, ny, nz, px, py, pz; uint32_t first, nv; };
+struct Vert2 { double x, y; };
+struct TriRec { double nx, ny, nz, cx, cy, cz, ax, ay, bx, by, ex, ey; };
 
-    // sphere.rs:27-61
-    for (uint32_t i = 0; i < sc.H.n_spheres; i++) {
-        const double *sp = S + sc.H.off_spheres + RM_SPHERE_WORDS * i;
-        V3 line = mk(sp[0] - o.x, sp[1] - o.y, sp[2] - o.z);
-        double r2 = sp[3];
-        double tca = dot(line, d);
-        double d2 = dot(line, line) - tca * tca;
-        if (d2 > r2) continue;
-        double thc = __builtin_sqrt(r2 - d2);
-        double t0 = tca - thc;
-        double t1 = tca + thc;
-        if (t0 < 0.) t0 = t1;
-        if (t0 < 0.) continue;
-        V3 p = o + scaled(d, t0);
-        V3 dp = p - o;
-        double dist = dot(dp, dp);                       // shapes.rs:128
-        if (closer(sc, hit, dist, best, i, best_pid)) { hit = true; best = dist; best_t = t0; best_pid = i; }
-    }
+__device__ __forceinline__ SphereRec load_sphere(const double *__restrict__ S, const rm_dev_header &H, uint32_t i) {
+    const double *sp = S + H.off_spheres + RM_SPHERE_WORDS * i;
+    return SphereRec{sp[0], sp[1], sp[2], sp[3]};
+}
+__device__ __forceinline__ PolyRec load_polygon(const double *__restrict__ S, const rm_dev_header &H, uint32_t i) {
+    const double *pg = S + H.off_polygons + RM_POLYGON_WORDS * i;
+    const uint32_t *u = reinterpret_cast<const uint32_t *>(pg + 6);
+    return PolyRec{pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], u[0], u[1]};
+}
+__device__ __forceinline__ Vert2 load_vertex(const double *__restrict__ S, const rm_dev_header &H, uint32_t v) {
+    const double *pv = S + H.off_pverts + RM_PVERT_WORDS * v;
+    return Vert2{pv[0], pv[1]};
+}
+__device__ __forceinline__ TriRec load_triangle(const double *__restrict__ S, const rm_dev_header &H, uint32_t i) {
+    const double *t = S + H.off_triangles + RM_TRIANGLE_WORDS * i;
+    return TriRec{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]};
+}
 
-    // polygon.rs:60-98
-    for (uint32_t i = 0; i < sc.H.n_polygons; i++) {
-        const double *pg = S + sc.H.off_polygons + RM_POLYGON_WORDS * i;
-        V3 n = mk(pg[0], pg[1], pg[2]);
-        V3 pp = mk(pg[3], pg[4], pg[5]);
-        const uint32_t first = reinterpret_cast<const uint32_t *>(pg + 6)[0];
-        const uint32_t nv = reinterpret_cast<const uint32_t *>(pg + 6)[1];
-        double dotprod = dot(d, n);
-        bool alive = !(dotprod == 0.);
-        double dist = dot(pp - o, n) / dotprod;
-        alive = alive && !(dist < 0.);
-        V3 p = o + scaled(d, dist);
-        const double *pv = S + sc.H.off_pverts + RM_PVERT_WORDS * first;
-        double ax = pv[0] - p.x, ay = pv[1] - p.y;       // vertex 0 relative to the hit point
-        const double ax0 = ax, ay0 = ay;
-        for (uint32_t e = 0; e < nv; e++) {
-            double bx, by;
-            if (e + 1 < nv) { bx = pv[2 * (e + 1)] - p.x; by = pv[2 * (e + 1) + 1] - p.y; }
-            else            { bx = ax0; by = ay0; }
-            // polygon.rs:54-56: ((v_i - p) x (v_{i+1} - p)).z > 0
+// sphere.rs:27-61 up to the discriminant: tca and d2 for one sphere
+__device__ __forceinline__ void sphere_setup(const SphereRec &s, V3 o, V3 d, double &tca, double &d2) {
+    const V3 line = mk(s.cx - o.x, s.cy - o.y, s.cz - o.z);
+    tca = dot(line, d);
+    d2 = dot(line, line) - tca * tca;
+}
+
+// polygon.rs:60-98: plane hit + 2-D inside test (polygon.rs:54-56: only the z of
+// (v_i - p) x (v_{i+1} - p), i.e. x and y of the vertices).  `q` holds the first four
+// vertices of the polygon (uploaded scenes pad the pool so the read is in bounds).
+__device__ __forceinline__ bool polygon_hit(const double *__restrict__ S, const rm_dev_header &H, const PolyRec &g,
+                                            const Vert2 (&q)[4], V3 o, V3 d, double &dist, V3 &p) {
+    const V3 n = mk(g.nx, g.ny, g.nz);
+    const double dotprod = dot(d, n);
+    const double num = dot(mk(g.px - o.x, g.py - o.y, g.pz - o.z), n);
+    // :66 parallel, :71-76 `dist = num / dotprod; if dist < 0 -> None`.  The quotient is
+    // negative exactly when the signs differ (|dotprod| <= 1, so no underflow to -0 while
+    // |num| > 1e-300): such lanes are rejected before the division and the edge tests,
+    // and a wave whose lanes are all rejected skips them altogether.
+    bool alive = !(dotprod == 0.) && !((num < -1e-300 && dotprod > 0.) || (num > 1e-300 && dotprod < 0.));
+    if (!__any(alive)) return false;
+    dist = num / dotprod;
+    alive = alive && !(dist < 0.);
+    p = o + scaled(d, dist);
+    const double x0 = q[0].x - p.x, y0 = q[0].y - p.y;
+    const double x1 = q[1].x - p.x, y1 = q[1].y - p.y;
+    const double x2 = q[2].x - p.x, y2 = q[2].y - p.y;
+    alive = alive && (x0 * y1 - y0 * x1 > 0.);
+    alive = alive && (x1 * y2 - y1 * x2 > 0.);
+    if (g.nv == 3u) {
+        alive = alive && (x2 * y0 - y2 * x0 > 0.);
+    } else {
+        double ax = q[3].x - p.x, ay = q[3].y - p.y;
+        alive = alive && (x2 * ay - y2 * ax > 0.);
+        for (uint32_t e = 4; e < g.nv; e++) {                         // pentagons and up
+            const Vert2 v = load_vertex(S, H, g.first + e);
+            const double bx = v.x - p.x, by = v.y - p.y;
             alive = alive && (ax * by - ay * bx > 0.);
             ax = bx; ay = by;
         }
-        if (!alive) continue;
-        V3 dp = p - o;
-        double dh = dot(dp, dp);
-        const uint32_t pid = sc.H.n_spheres + i;
-        if (closer(sc, hit, dh, best, pid, best_pid)) { hit = true; best = dh; best_t = dist; best_pid = pid; }
+        alive = alive && (ax * y0 - ay * x0 > 0.);
+    }
+    return alive;
+}
+
+// triangle.rs:49-83
+__device__ __forceinline__ bool triangle_hit(const TriRec &t, V3 o, V3 d, double &dist, V3 &p) {
+    const V3 n = mk(t.nx, t.ny, t.nz);
+    const double dotprod = dot(d, n);
+    const double num = dot(mk(t.cx - o.x, t.cy - o.y, t.cz - o.z), n);
+    // :57 parallel, :62-67 going away -- same early sign test as polygon_hit
+    bool alive = !(__builtin_fabs(dotprod) < 1e-6) &&
+                 !((num < -1e-300 && dotprod > 0.) || (num > 1e-300 && dotprod < 0.));
+    if (!__any(alive)) return false;
+    dist = num / dotprod;
+    alive = alive && !(dist < 0.);
+    p = o + scaled(d, dist);
+    const double ax = t.ax - p.x, ay = t.ay - p.y;
+    const double bx = t.bx - p.x, by = t.by - p.y;
+    const double cx = t.ex - p.x, cy = t.ey - p.y;
+    alive = alive && (ax * by - ay * bx > 0.);
+    alive = alive && (bx * cy - by * cx > 0.);
+    alive = alive && (cx * ay - cy * ax > 0.);
+    return alive;
+}
+
+// ---- closest hit ---------------------------------------------------------
+struct ClosestState {
+    bool hit;
+    double best, best_t;
+    uint32_t best_pid;
+};
+
+__device__ __forceinline__ void closest_sphere(const SceneView &sc, ClosestState &c, const SphereRec &s, uint32_t pid,
+                                               V3 o, V3 d) {
+    double tca, d2;
+    sphere_setup(s, o, d, tca, d2);
+    if (d2 > s.r2) return;                                           // sphere.rs:37
+    const double thc = __builtin_sqrt(s.r2 - d2);
+    double t0 = tca - thc;
+    const double t1 = tca + thc;
+    if (t0 < 0.) t0 = t1;
+    if (t0 < 0.) return;
+    const V3 p = o + scaled(d, t0);
+    const V3 dp = p - o;
+    const double dist = dot(dp, dp);                                 // shapes.rs:128
+    if (closer(sc, c.hit, dist, c.best, pid, c.best_pid)) { c.hit = true; c.best = dist; c.best_t = t0; c.best_pid = pid; }
+}
+
+__device__ __forceinline__ bool closest_hit(const SceneView &sc, V3 o, V3 d, Hit &out) {
+    const double *__restrict__ S = sc.G;
+    const rm_dev_header &H = sc.H;
+    ClosestState c{false, 0., 0., 0u};
+
+    uint32_t i = 0;
+    for (; i + 4u <= H.n_spheres; i += 4u) {
+        const SphereRec s0 = load_sphere(S, H, i), s1 = load_sphere(S, H, i + 1u);
+        const SphereRec s2 = load_sphere(S, H, i + 2u), s3 = load_sphere(S, H, i + 3u);
+        closest_sphere(sc, c, s0, i, o, d);
+        closest_sphere(sc, c, s1, i + 1u, o, d);
+        closest_sphere(sc, c, s2, i + 2u, o, d);
+        closest_sphere(sc, c, s3, i + 3u, o, d);
+    }
+    for (; i < H.n_spheres; i++) closest_sphere(sc, c, load_sphere(S, H, i), i, o, d);
+
+    for (uint32_t g = 0; g < H.n_polygons; g++) {
+        const PolyRec pg = load_polygon(S, H, g);
+        const Vert2 q[4] = {load_vertex(S, H, pg.first), load_vertex(S, H, pg.first + 1u),
+                            load_vertex(S, H, pg.first + 2u), load_vertex(S, H, pg.first + 3u)};
+        double dist;
+        V3 p;
+        if (!polygon_hit(S, H, pg, q, o, d, dist, p)) continue;
+        const V3 dp = p - o;
+        const double dh = dot(dp, dp);
+        const uint32_t pid = H.n_spheres + g;
+        if (closer(sc, c.hit, dh, c.best, pid, c.best_pid)) { c.hit = true; c.best = dh; c.best_t = dist; c.best_pid = pid; }
     }
 
-    // triangle.rs:49-83 inside obj.rs:193-210
-    for (uint32_t i = 0; i < sc.H.n_triangles; i++) {
-        const double *tr = S + sc.H.off_triangles + RM_TRIANGLE_WORDS * i;
-        V3 n = mk(tr[0], tr[1], tr[2]);
-        V3 c = mk(tr[3], tr[4], tr[5]);
-        double dotprod = dot(d, n);
-        bool alive = !(__builtin_fabs(dotprod) < 1e-6);
-        double dist = dot(c - o, n) / dotprod;
-        alive = alive && !(dist < 0.);
-        V3 p = o + scaled(d, dist);
-        double ax = tr[6] - p.x, ay = tr[7] - p.y;
-        double bx = tr[8] - p.x, by = tr[9] - p.y;
-        double cx = tr[10] - p.x, cy = tr[11] - p.y;
-        alive = alive && (ax * by - ay * bx > 0.);
-        alive = alive && (bx * cy - by * cx > 0.);
-        alive = alive && (cx * ay - cy * ax > 0.);
-        if (!alive) continue;
-        V3 dp = p - o;
-        double dh = dot(dp, dp);
-        const uint32_t pid = sc.H.n_spheres + sc.H.n_polygons + i;
-        if (closer(sc, hit, dh, best, pid, best_pid)) { hit = true; best = dh; best_t = dist; best_pid = pid; }
+    // obj.rs:193-210: closest triangle, strict `<`
+    auto tri = [&](const TriRec &t, uint32_t k) {
+        double dist;
+        V3 p;
+        if (!triangle_hit(t, o, d, dist, p)) return;
+        const V3 dp = p - o;
+        const double dh = dot(dp, dp);
+        const uint32_t pid = H.n_spheres + H.n_polygons + k;
+        if (closer(sc, c.hit, dh, c.best, pid, c.best_pid)) { c.hit = true; c.best = dh; c.best_t = dist; c.best_pid = pid; }
+    };
+    uint32_t k = 0;
+    for (; k + 2u <= H.n_triangles; k += 2u) {
+        const TriRec t0 = load_triangle(S, H, k), t1 = load_triangle(S, H, k + 1u);
+        tri(t0, k);
+        tri(t1, k + 1u);
     }
+    for (; k < H.n_triangles; k++) tri(load_triangle(S, H, k), k);
 
-    out.t = best_t;
-    out.pid = best_pid;
-    return hit;
+    out.t = c.best_t;
+    out.pid = c.best_pid;
+    return c.hit;
 }
 
 // ---- any hit (shadow rays) -------------------------------------------------
 // shapes.rs:92-108.  The answer does not depend on visiting order.  A lane that
 // has found an occluder keeps walking with its result latched; the wave leaves
-// a loop early once every active lane is occluded.
+// a loop early once every active lane is occluded (one vote per batch).
+__device__ __forceinline__ bool shadow_sphere(const SphereRec &s, V3 o, V3 d) {
+    double tca, d2;
+    sphere_setup(s, o, d, tca, d2);
+    if (d2 > s.r2) return false;
+    // sphere.rs:43-52: hit unless both roots are negative.  thc >= 0, so tca >= 0
+    // already gives t1 = tca + thc >= 0 without the square root.
+    if (!(tca < 0.)) return true;
+    const double thc = __builtin_sqrt(s.r2 - d2);
+    double t0 = tca - thc;
+    const double t1 = tca + thc;
+    if (t0 < 0.) t0 = t1;
+    return !(t0 < 0.);
+}
+
 __device__ __forceinline__ bool any_hit(const SceneView &sc, V3 o, V3 d) {
     const double *__restrict__ S = sc.G;
+    const rm_dev_header &H = sc.H;
     bool occ = false;
 
-    for (uint32_t i = 0; i < sc.H.n_spheres; i++) {
-        const double *sp = S + sc.H.off_spheres + RM_SPHERE_WORDS * i;
-        V3 line = mk(sp[0] - o.x, sp[1] - o.y, sp[2] - o.z);
-        double r2 = sp[3];
-        double tca = dot(line, d);
-        double d2 = dot(line, line) - tca * tca;
-        if (!occ && !(d2 > r2)) {
-            // sphere.rs:43-52: hit unless both roots are negative.  thc >= 0, so
-            // tca >= 0 already gives t1 = tca + thc >= 0 without the square root.
-            if (!(tca < 0.)) {
-                occ = true;
-            } else {
-                double thc = __builtin_sqrt(r2 - d2);
-                double t0 = tca - thc;
-                double t1 = tca + thc;
-                if (t0 < 0.) t0 = t1;
-                if (!(t0 < 0.)) occ = true;
-            }
-        }
+    uint32_t i = 0;
+    for (; i + 4u <= H.n_spheres; i += 4u) {
+        const SphereRec s0 = load_sphere(S, H, i), s1 = load_sphere(S, H, i + 1u);
+        const SphereRec s2 = load_sphere(S, H, i + 2u), s3 = load_sphere(S, H, i + 3u);
+        occ = occ || shadow_sphere(s0, o, d);
+        occ = occ || shadow_sphere(s1, o, d);
+        occ = occ || shadow_sphere(s2, o, d);
+        occ = occ || shadow_sphere(s3, o, d);
+        if (__all(occ)) return true;
+    }
+    for (; i < H.n_spheres; i++) occ = occ || shadow_sphere(load_sphere(S, H, i), o, d);
+    if (__all(occ)) return true;
+
+    for (uint32_t g = 0; g < H.n_polygons; g++) {
+        const PolyRec pg = load_polygon(S, H, g);
+        const Vert2 q[4] = {load_vertex(S, H, pg.first), load_vertex(S, H, pg.first + 1u),
+                            load_vertex(S, H, pg.first + 2u), load_vertex(S, H, pg.first + 3u)};
+        double dist;
+        V3 p;
+        occ = occ || polygon_hit(S, H, pg, q, o, d, dist, p);
         if (__all(occ)) return true;
     }
 
-    for (uint32_t i = 0; i < sc.H.n_polygons; i++) {
-        const double *pg = S + sc.H.off_polygons + RM_POLYGON_WORDS * i;
-        V3 n = mk(pg[0], pg[1], pg[2]);
-        V3 pp = mk(pg[3], pg[4], pg[5]);
-        const uint32_t first = reinterpret_cast<const uint32_t *>(pg + 6)[0];
-        const uint32_t nv = reinterpret_cast<const uint32_t *>(pg + 6)[1];
-        double dotprod = dot(d, n);
-        bool alive = !(dotprod == 0.);
-        double dist = dot(pp - o, n) / dotprod;
-        alive = alive && !(dist < 0.);
-        V3 p = o + scaled(d, dist);
-        const double *pv = S + sc.H.off_pverts + RM_PVERT_WORDS * first;
-        double ax = pv[0] - p.x, ay = pv[1] - p.y;
-        const double ax0 = ax, ay0 = ay;
-        for (uint32_t e = 0; e < nv; e++) {
-            double bx, by;
-            if (e + 1 < nv) { bx = pv[2 * (e + 1)] - p.x; by = pv[2 * (e + 1) + 1] - p.y; }
-            else            { bx = ax0; by = ay0; }
-            alive = alive && (ax * by - ay * bx > 0.);
-            ax = bx; ay = by;
-        }
-        occ = occ || alive;
+    uint32_t k = 0;
+    for (; k + 2u <= H.n_triangles; k += 2u) {
+        const TriRec t0 = load_triangle(S, H, k), t1 = load_triangle(S, H, k + 1u);
+        double dist;
+        V3 p;
+        occ = occ || triangle_hit(t0, o, d, dist, p);
+        occ = occ || triangle_hit(t1, o, d, dist, p);
         if (__all(occ)) return true;
     }
-
-    for (uint32_t i = 0; i < sc.H.n_triangles; i++) {
-        const double *tr = S + sc.H.off_triangles + RM_TRIANGLE_WORDS * i;
-        V3 n = mk(tr[0], tr[1], tr[2]);
-        V3 c = mk(tr[3], tr[4], tr[5]);
-        double dotprod = dot(d, n);
-        bool alive = !(__builtin_fabs(dotprod) < 1e-6);
-        double dist = dot(c - o, n) / dotprod;
-        alive = alive && !(dist < 0.);
-        V3 p = o + scaled(d, dist);
-        double ax = tr[6] - p.x, ay = tr[7] - p.y;
-        double bx = tr[8] - p.x, by = tr[9] - p.y;
-        double cx = tr[10] - p.x, cy = tr[11] - p.y;
-        alive = alive && (ax * by - ay * bx > 0.);
-        alive = alive && (bx * cy - by * cx > 0.);
-        alive = alive && (cx * ay - cy * ax > 0.);
-        occ = occ || alive;
-        if (__all(occ)) return true;
+    for (; k < H.n_triangles; k++) {
+        double dist;
+        V3 p;
+        occ = occ || triangle_hit(load_triangle(S, H, k), o, d, dist, p);
     }
     return occ;
 }
