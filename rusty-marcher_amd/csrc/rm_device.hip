@@ -18,11 +18,8 @@
 
 using namespace rmdev;
 
-#ifndef RM_WAVES_PER_SIMD
-#define RM_WAVES_PER_SIMD 1
-#endif
 #ifndef RM_BUILD_FLAVOR
-#define RM_BUILD_FLAVOR "strict-fp64"
+#define RM_BUILD_FLAVOR "fp64 strict+fast"
 #endif
 
 // With max_depth == 0 the primary ray itself is capped: every pixel is the
@@ -119,6 +116,7 @@ struct rm_ctx {
     rm_vec3 camera{0., 0., 0.};
     bool integer_exponents = false;   // every material's specular_exponent is a small non-negative integer
     bool force_generic_pow = false;   // RM_FORCE_GENERIC_POW=1 (A/B knob)
+    bool force_strict_fp = false;     // RM_FORCE_STRICT_FP=1 (A/B knob; same as RM_FLAG_STRICT_FP on every call)
     // Bottom-up by default: workgroups are dispatched in id order and the drain at the end
     // of a launch runs at low occupancy, so the rows that are expensive in the
     // reference's scenes (ground, objects resting on it) go first and the cheap sky rows
@@ -155,11 +153,15 @@ static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 64 * 1024;
 
 // Kernel instantiation table: stack depth x pow flavour for one launch geometry.
 template <int W, int T>
-static const void *pick_static(int stack, int pow_mode) {
-#define RM_ROW(S)                                                               \
-    if (stack == S)                                                             \
-        return pow_mode == POW_INTEGER ? (const void *)rm_render_static<S, POW_INTEGER, W, T> \
-                                       : (const void *)rm_render_static<S, POW_GENERIC, W, T>;
+static const void *pick_static(int stack, int pow_mode, bool fast) {
+#define RM_ROW(S)                                                                                    \
+    if (stack == S) {                                                                                \
+        if (fast)                                                                                    \
+            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, T>   \
+                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, T>;  \
+        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, T>     \
+                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, T>;    \
+    }
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
     return nullptr;
@@ -205,6 +207,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc(&ctx->d_max, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if (const char *env = std::getenv("RM_FORCE_GENERIC_POW")) ctx->force_generic_pow = env[0] == '1';
+    if (const char *env = std::getenv("RM_FORCE_STRICT_FP")) ctx->force_strict_fp = env[0] == '1';
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -434,6 +437,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     KernelArgs a{};
     a.H = ctx->H;
     a.half_fov = p->half_fov; a.height = p->height; a.width = p->width; a.ratio = p->ratio;
+    a.inv_width = 1. / p->width; a.inv_height = 1. / p->height;
     a.cam_x = ctx->camera.x; a.cam_y = ctx->camera.y; a.cam_z = ctx->camera.z;
     a.bg_x = p->background.x; a.bg_y = p->background.y; a.bg_z = p->background.z;
     a.frame_width = p->frame_width;
@@ -465,11 +469,12 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     const int stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
     const int pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
 
+    const bool fast = !(p->flags & RM_FLAG_STRICT_FP) && !ctx->force_strict_fp;
     const void *fn = nullptr;
-    if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode);
-    else if (m.waves == 4 && m.per_wave == 1) fn = pick_static<4, 1>(stack, pow_mode);
-    else if (m.waves == 1 && m.per_wave == 4) fn = pick_static<1, 4>(stack, pow_mode);
-    else if (m.waves == 4 && m.per_wave == 4) fn = pick_static<4, 4>(stack, pow_mode);
+    if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode, fast);
+    else if (m.waves == 4 && m.per_wave == 1) fn = pick_static<4, 1>(stack, pow_mode, fast);
+    else if (m.waves == 1 && m.per_wave == 4) fn = pick_static<1, 4>(stack, pow_mode, fast);
+    else if (m.waves == 4 && m.per_wave == 4) fn = pick_static<4, 4>(stack, pow_mode, fast);
     else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE");
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
     const dim3 grid((a.n_tiles + per_wg - 1) / per_wg);

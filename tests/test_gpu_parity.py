@@ -3,8 +3,9 @@ against the CPU oracle on the same inputs, the committed golden file, and
 size-independent properties at BASELINE.json's full sizes.
 
 Tolerance: BASELINE.json's north star asks per-channel |delta| < 1e-4 on every pixel.
-The kernel computes in binary64 in the reference's operation order, so the tests also
-hold it to TIGHT = 1e-9 (the only non-identical operation is pow: device libm vs glibc).
+The kernel computes in binary64, so the tests hold BOTH numeric flavours to TIGHT = 1e-9:
+strict (the reference's operations in its order; differs only through pow) and the
+default fast flavour (FMA contraction, Newton rsqrt, hits ordered by ray parameter).
 """
 import ctypes as C
 import hashlib
@@ -18,6 +19,19 @@ pytestmark = pytest.mark.gpu
 
 NORTH_STAR_TOL = 1e-4
 TIGHT = 1e-9
+
+RM_FLAG_STRICT_FP = 1
+_FLAGS = {"value": 0}
+
+
+@pytest.fixture(autouse=True, params=["fast", "strict"])
+def flavour(request):
+    """Every test runs against both numeric flavours of the kernel: the default
+    (FMA, Newton rsqrt, hits ordered by t) and RM_FLAG_STRICT_FP (the reference's
+    operations one by one)."""
+    _FLAGS["value"] = RM_FLAG_STRICT_FP if request.param == "strict" else 0
+    yield request.param
+    _FLAGS["value"] = 0
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +47,7 @@ def gpu_render(pkg, ctx, scene, w, h, depth, band=None, out=None, fov=workloads.
     handle = scene.flatten()
     ctx.upload(handle)
     p = pkg.backend.make_params(fov, float(h), float(w), depth, band)
+    p.flags = _FLAGS["value"]
     if out is None:
         out = np.zeros((h, w, 3), dtype=np.float64)
     t = ctx.render(p, out)
