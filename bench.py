@@ -118,14 +118,10 @@ def main():
     def gather():
         workloads.gather_bands(dist, frame, n_rows, rank, world)
 
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record(stream)
+    def step():
         st = L.rm_render_device(ctx.ptr, p_ref, frame_ptr, stream_ptr)
         if st != 0:
             raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
-        if ev is not None:
-            ev[1].record(stream)
         if world > 1:
             gather()
 
@@ -137,12 +133,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
+    # HIP events on the launch stream bracket the timed region (one pair: an event per
+    # launch would put two extra packets between consecutive kernels)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
+    ev0.record(stream)
     for k in range(args.steps):
-        step(events[k])
+        step()
+    ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -151,7 +150,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))   # this rank's kernel
+    # average launch duration of this rank's render kernel over the timed region (for
+    # N > 1 the gather's stream time is inside the bracket too, so it is only reported
+    # as the kernel's duration at N = 1)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
     px_launch = (band[1] - band[0]) * 32 * w                            # pixels one launch writes
 
     if rank == 0:
