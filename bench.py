@@ -6,11 +6,13 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step is one frame of the workload: BASELINE.json's configs[1] (demo scene,
-1920x1080, depth cap 5) unless --config says otherwise.  The frame stays in HBM
-(device-resident framebuffer); inputs (the scene) are uploaded before the timed region.
-N > 1: the frame is sharded by 32-row patch bands, every rank renders
-its band and the bands are gathered into rank 0's framebuffer over RCCL inside the
-timed region -- total work is fixed, so scaling is "strong".
+1920x1080, depth cap 5) unless --config says otherwise.  Each launch writes the f64 RGB
+frame (the reference's FrameBuffer) and its display bytes (`to_vec`, what the UI blits)
+to HBM; inputs (the scene) are uploaded before the timed region.
+N > 1: the frame is sharded by equal bands of 32-row patch rows, every
+rank renders its band, and ONE in-place RCCL all-gather per frame, inside the timed
+region, completes the display frame on every rank (--payload u8, default; rank 0 is
+the consumer) or the f64 frame (--payload f64).  Total work is fixed: "strong" scaling.
 
 Rank 0 prints ONE JSON line.  Metric definition follows the reference
 (renderer.rs:113-120): frame_width x frame_height pixels per frame / wall time.
@@ -72,6 +74,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", help="workload id from workloads.CONFIGS")
+    ap.add_argument("--payload", choices=["u8", "f64"], default="u8",
+                    help="what the per-frame all-gather moves at N > 1: the display bytes (to_vec, 3 B/px) "
+                         "or the f64 rows (24 B/px)")
+    ap.add_argument("--strict-fp", action="store_true", help="RM_FLAG_STRICT_FP flavour of the kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
     args = ap.parse_args()
@@ -98,14 +104,23 @@ def main():
     cfg = workloads.CONFIGS[args.config]
     w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
     n_rows = h // 32
-    band = workloads.patch_rows_for_rank(n_rows, rank, world)
+    c_rows, bands = workloads.equal_bands(n_rows, world)
+    band = bands[rank]
 
     ctx = pkg.backend.Context(local_rank)
     scene = workloads.product_scene(pkg, cfg["scene"])
     ctx.upload(scene.flatten())
     params = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
-    frame = torch.zeros((h, w, 3), dtype=torch.float64, device=dev)     # create_frame_buffer zero-fills
-    # A dedicated stream: the kernel, the timing events and the RCCL ops are all ordered
+    if args.strict_fp:
+        params.flags = 1                                               # RM_FLAG_STRICT_FP
+    # Per rank: the f64 frame (create_frame_buffer zero-fills; this rank's band of it is
+    # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
+    # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
+    pad_h = max(h, world * c_rows * 32)
+    frame = torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev)
+    frame8 = torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev)
+    gathered = (frame8 if args.payload == "u8" else frame)[:world * c_rows * 32]
+    # A dedicated stream: the kernel, the timing events and the RCCL op are all ordered
     # on it (torch.cuda.Event only sees the stream it is recorded on).
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
@@ -113,17 +128,19 @@ def main():
     L = pkg.lib()
     p_ref = C.byref(params)
     frame_ptr = C.c_void_p(frame.data_ptr())
+    frame8_ptr = C.c_void_p(frame8.data_ptr())
     stream_ptr = C.c_void_p(stream.cuda_stream)
-
-    def gather():
-        workloads.gather_bands(dist, frame, n_rows, rank, world)
+    has_rows = band[1] > band[0]
 
     def step():
-        st = L.rm_render_device(ctx.ptr, p_ref, frame_ptr, stream_ptr)
-        if st != 0:
-            raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
+        """One frame: render this rank's band (f64 rows + their display bytes), then the
+        single collective of the frame."""
+        if has_rows:
+            st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptr, frame8_ptr, stream_ptr)
+            if st != 0:
+                raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
         if world > 1:
-            gather()
+            workloads.allgather_bands(dist, gathered, rank, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -177,12 +194,16 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s scene %dx%d, depth cap %d, fov 1.5, device-resident f64 RGB frame"
                                    % (args.config, cfg["scene"], w, h, depth),
-                       "sharding": "row bands of 32-px patch rows, %d rank(s)%s"
-                                   % (world, ", RCCL send/recv gather to rank 0 per frame" if world > 1 else ""),
+                       "sharding": "row bands of %d patch rows (32 px) per rank, %d rank(s)%s"
+                                   % (c_rows, world, (", one in-place RCCL all-gather of the %s rows per frame; "
+                                                      "f64 rows stay in each rank's HBM" % args.payload)
+                                      if world > 1 else ""),
+                       "outputs": "f64 RGB frame [H][W][3] + u8 display frame (to_vec) per launch",
+                       "numerics": "strict" if args.strict_fp else "fast",
                        "build": L.rm_build_info().decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rm_render_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "rmdev_fast::rm_render_static" if not args.strict_fp else "rmdev_strict::rm_render_static", "kernel_ms": kernel_ms,
                          "bytes_per_launch": px_launch * BYTES_PER_PIXEL,
                          "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); "
                                  "achieved = 24 B x pixels written / kernel time"},
@@ -190,7 +211,10 @@ def main():
         if args.check:
             O = G.load_oracle()
             ref = O.render(workloads.oracle_scene(O, cfg["scene"]), w, h, max_depth=depth)
-            out["max_abs_delta_vs_oracle"] = float(np.abs(frame.cpu().numpy() - ref).max())
+            got = frame[:h].cpu().numpy()
+            out["max_abs_delta_vs_oracle"] = float(np.abs(got[:n_rows * 32] - ref[:n_rows * 32]).max()) if world == 1 else None
+            u8 = frame8[:n_rows * 32].cpu().numpy().reshape(-1)
+            out["display_bytes_differing_from_oracle"] = int((u8 != O.to_vec(ref[:n_rows * 32].copy())).sum())
         if world == 1 and not args.no_cpu_baseline:
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, cfg)

@@ -222,6 +222,17 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
  */
 rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream);
 
+/*
+ * rm_render_device that ALSO writes the band's display bytes: device_rgb8 is a
+ * [frame_height][frame_width][3] byte buffer receiving `fb.to_vec()` of the rendered
+ * pixels (framebuffer.rs:40-55: (255 * clamp(f, 0, 1)) as u8, no normalisation -- what
+ * update_raytrace_image hands to the pixbuf, main.rs:337-346), fused into the kernel's
+ * epilogue.  3 B/pixel instead of 24: the payload a multi-GPU gather or a D2H copy for
+ * display needs.  max_depth must be >= 1.
+ */
+rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
+                              void *hip_stream);
+
 /* Device framebuffer of the last rm_render(.., NULL, ..) and its size in bytes. */
 rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes);
 

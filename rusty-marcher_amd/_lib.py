@@ -102,6 +102,7 @@ SIGNATURES = {
     "rm_camera_update": (C.c_int, [_VP, rm_vec3]),
     "rm_render": (C.c_int, [_VP, _P(rm_params), _P(C.c_double), _P(rm_timing)]),
     "rm_render_device": (C.c_int, [_VP, _P(rm_params), _VP, _VP]),
+    "rm_render_device_u8": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP]),
     "rm_device_framebuffer": (C.c_int, [_VP, _P(_VP), _P(C.c_size_t)]),
     "rm_postprocess": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_int, _P(C.c_uint8), _P(C.c_double)]),
     "rm_abi_version": (C.c_uint32, []),

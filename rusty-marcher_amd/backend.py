@@ -43,6 +43,11 @@ class Context:
         _lib.check(self.L.rm_render_device(self.ptr, C.byref(params), C.c_void_p(device_ptr),
                                            C.c_void_p(stream) if stream else None), self.ptr)
 
+    def render_device_u8(self, params, device_ptr, device_ptr8, stream=None):
+        _lib.check(self.L.rm_render_device_u8(self.ptr, C.byref(params), C.c_void_p(device_ptr),
+                                              C.c_void_p(device_ptr8), C.c_void_p(stream) if stream else None),
+                   self.ptr)
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, lds = C.c_int(0), C.c_size_t(0)

@@ -423,7 +423,7 @@ static rm_status check_params(rm_ctx *ctx, const rm_params *p, uint32_t *row_beg
 }
 
 static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_begin, uint32_t row_end, double *d_frame,
-                               hipStream_t stream) {
+                               uint8_t *d_frame8, hipStream_t stream) {
     if (row_begin == row_end) return RM_OK;
     const uint32_t n_width = p->frame_width / RM_PATCH_SIZE;
     if (p->max_depth == 0) {
@@ -446,6 +446,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     a.n_width = n_width;
     a.n_tiles = (row_end - row_begin) * n_width * 16u;
     a.debug_stamps = nullptr;
+    a.frame8 = d_frame8;
     // dispatch order: tile = (id * order_mul + order_add) % n_tiles, a bijection
     a.order_mul = 1; a.order_add = 0;
     if (ctx->tile_order == TILE_ORDER_REVERSE && a.n_tiles > 1) {             // id -> n-1-id
@@ -508,7 +509,20 @@ rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rg
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)hip_stream;   // NULL is HIP's default stream, as in any HIP API
-    return launch_render(ctx, params, b, e, (double *)device_rgb, s);
+    return launch_render(ctx, params, b, e, (double *)device_rgb, nullptr, s);
+}
+
+rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
+                              void *hip_stream) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render_device_u8: NULL ctx");
+    if (!device_rgb || !device_rgb8) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render_device_u8: NULL device buffer");
+    uint32_t b = 0, e = 0;
+    rm_status st = check_params(ctx, params, &b, &e);
+    if (st != RM_OK) return st;
+    if (params->max_depth == 0)
+        return ctx_fail(ctx, RM_ERR_DEPTH, "rm_render_device_u8: max_depth 0 renders no ray; use rm_render_device + rm_postprocess");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_render(ctx, params, b, e, (double *)device_rgb, (uint8_t *)device_rgb8, (hipStream_t)hip_stream);
 }
 
 rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing) {
@@ -534,7 +548,7 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     }
 
     RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    st = launch_render(ctx, params, b, e, ctx->d_frame, ctx->stream);
+    st = launch_render(ctx, params, b, e, ctx->d_frame, nullptr, ctx->stream);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 

@@ -48,6 +48,7 @@ struct KernelArgs {
     uint32_t order_mul;                      // dispatch order: tile = (id * order_mul + order_add) % n_tiles
     uint32_t order_add;
     uint32_t _pad;
+    uint8_t *frame8;                         // optional [H][W][3] u8 display frame (NULL: not written)
     unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
 };
 

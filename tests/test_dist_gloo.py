@@ -67,3 +67,65 @@ def test_band_partition_properties():
             assert max(sizes) - min(sizes) <= 1
     # 8K has 135 patch rows -> 16 or 17 per rank on 8 GPUs
     assert sorted(set(e - b for b, e in (workloads.patch_rows_for_rank(135, r, 8) for r in range(8)))) == [16, 17]
+
+
+def _worker_allgather(rank, world, port, w, h, depth, payload, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    import workloads
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        O = G.load_oracle()
+        n_rows = h // 32
+        c, bands = workloads.equal_bands(n_rows, world)
+        b, e = bands[rank]
+        frame = np.zeros((max(h, world * c * 32), w, 3))
+        if e > b:
+            O.render(O.OracleScene.create_default(), w, h, max_depth=depth, n_threads=2, frame=frame[:h], band=(b, e))
+        if payload == "u8":
+            mine = torch.from_numpy(O.to_vec(frame.copy()).reshape(frame.shape))
+            # only this rank's rows may be trusted before the gather
+            padded = torch.full_like(mine, 77)
+            padded[rank * c * 32:(rank + 1) * c * 32] = mine[rank * c * 32:(rank + 1) * c * 32]
+        else:
+            padded = torch.full(frame.shape, -5.0, dtype=torch.float64)
+            padded[rank * c * 32:(rank + 1) * c * 32] = torch.from_numpy(frame)[rank * c * 32:(rank + 1) * c * 32]
+        workloads.allgather_bands(dist, padded[:world * c * 32], rank, world)
+        dist.barrier()
+        if rank == world - 1:            # every rank ends up with the frame; check a non-root one
+            np.save(out_path, padded.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,payload", [(2, 128, 100, "u8"), (3, 96, 128, "f64"), (4, 64, 96, "u8")])
+def test_equal_band_allgather(O, tmp_path, world, w, h, payload):
+    """bench.py's N > 1 path: equal bands + one in-place all_gather_into_tensor."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import workloads
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker_allgather, args=(world, _free_port(), w, h, 3, payload, out), nprocs=world, join=True)
+    got = np.load(out)
+    n_rows = h // 32
+    ref = O.render(O.OracleScene.create_default(), w, h, max_depth=3)
+    if payload == "u8":
+        assert np.array_equal(got[:n_rows * 32].reshape(-1), O.to_vec(ref[:n_rows * 32].copy()))
+    else:
+        assert np.array_equal(got[:n_rows * 32], ref[:n_rows * 32])
+
+
+def test_equal_bands_properties():
+    sys.path.insert(0, ROOT)
+    import workloads
+    for P in (0, 1, 7, 33, 128, 135):
+        for N in (1, 2, 3, 4, 8):
+            c, bands = workloads.equal_bands(P, N)
+            assert c * N >= P and (c - 1) * N < P or P == 0
+            assert bands[0][0] == 0 and bands[-1][1] == P
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(N - 1))
+            assert all(0 <= e - b <= c for b, e in bands)
+            assert all(b == min(r * c, P) for r, (b, e) in enumerate(bands))
+    assert workloads.equal_bands(33, 8)[1] == [(0, 5), (5, 10), (10, 15), (15, 20), (20, 25), (25, 30), (30, 33), (33, 33)]

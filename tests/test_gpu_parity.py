@@ -437,6 +437,34 @@ def test_render_device_into_torch_buffer(pkg, O, ctx):
     assert np.all(got[:64] == -3.) and np.all(got[288:] == -3.)
 
 
+def test_render_device_u8_display_bytes(pkg, O, ctx):
+    """rm_render_device_u8: the fused epilogue writes fb.to_vec() of the band
+    (framebuffer.rs:40-55: clamp, x255, truncate -- no normalisation) next to the f64 rows."""
+    import torch
+    w, h, depth = 640, 352, 5
+    ctx.upload(pkg.Scene.create_default().flatten())
+    f64 = torch.full((h, w, 3), -3., dtype=torch.float64, device="cuda:0")
+    u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+    p = pkg.backend.make_params(1.5, float(h), float(w), depth, band=(1, 10))
+    p.flags = _FLAGS["value"]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx.render_device_u8(p, f64.data_ptr(), u8.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    ref = np.full((h, w, 3), -3.)
+    O.render(O.OracleScene.create_default(), w, h, max_depth=depth, frame=ref, band=(1, 10))
+    compare(f64.cpu().numpy(), ref)
+    got8 = u8.cpu().numpy()
+    assert np.all(got8[:32] == 201) and np.all(got8[320:] == 201)          # outside the band: untouched
+    want8 = O.to_vec(ref[32:320].copy()).reshape(288, w, 3)
+    n_diff = int((got8[32:320] != want8).sum())
+    assert n_diff <= 2, "%d display bytes differ" % n_diff                 # truncation at k/255 +- 1 ulp
+    assert got8[32:320].max() == 255 and got8[32:320].min() == 0
+    p.max_depth = 0
+    with pytest.raises(pkg.BackendError):
+        ctx.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+
+
 # ---------------------------------------------------------------- post-process (8f.1)
 def test_postprocess_normalize_and_quantize(pkg, O, ctx):
     import torch

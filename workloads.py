@@ -157,3 +157,20 @@ def gather_bands(dist, frame, n_patch_rows, rank, world, dst=0):
     for req in reqs:
         req.wait()          # on CUDA streams this orders the stream, it does not block the host
     return reqs
+
+
+def equal_bands(n_patch_rows, world):
+    """Equal-size contiguous bands for an all-gather: every rank owns c = ceil(P/N) patch
+    rows' worth of frame rows, of which [begin, end) are real (trailing ranks may own
+    fewer, or none: P = 33, N = 8 -> 5,5,5,5,5,5,3,0).  The makespan equals that of the
+    balanced split (max band = c either way).  Returns (c, [(begin, end)] per rank)."""
+    c = -(-n_patch_rows // world) if n_patch_rows else 0
+    return c, [(min(r * c, n_patch_rows), min((r + 1) * c, n_patch_rows)) for r in range(world)]
+
+
+def allgather_bands(dist, padded, rank, world):
+    """The one collective per frame: `padded` is a [world*c*32, W, 3] tensor (any dtype) in
+    which this rank has filled rows [rank*c*32, (rank+1)*c*32); an in-place all-gather
+    (ncclAllGather on GPUs) completes it on every rank -- rank 0 is the consumer."""
+    rows = padded.shape[0] // world
+    dist.all_gather_into_tensor(padded, padded[rank * rows:(rank + 1) * rows])
