@@ -78,9 +78,17 @@ def main():
                     help="what the per-frame all-gather moves at N > 1: the display bytes (to_vec, 3 B/px) "
                          "or the f64 rows (24 B/px)")
     ap.add_argument("--strict-fp", action="store_true", help="RM_FLAG_STRICT_FP flavour of the kernel")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the per-frame collective even at world size 1 (smoke test of the N > 1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when its
+    # communicator comes up, so everything else in this process goes to stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -97,8 +105,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     pkg = G.load_package()
     cfg = workloads.CONFIGS[args.config]
@@ -139,12 +150,12 @@ def main():
             st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptr, frame8_ptr, stream_ptr)
             if st != 0:
                 raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
-        if world > 1:
+        if use_dist:
             workloads.allgather_bands(dist, gathered, rank, world)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +174,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -219,9 +230,10 @@ def main():
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, cfg)
             out["speedup_vs_cpu_baseline"] = mpx / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
