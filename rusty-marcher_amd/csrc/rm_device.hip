@@ -462,7 +462,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     // larger ones share the LDS copy of the scene between four waves
     rm_launch_mode m = ctx->mode;
     if (m.waves == 0) { m.waves = (size_t)ctx->H.total_words * sizeof(double) <= 4096 ? 1 : 4; m.per_wave = 1; }
-    const size_t lds = (size_t)ctx->H.total_words * sizeof(double) + (size_t)m.waves * 64 * 3 * sizeof(double);
+    const size_t lds = ((size_t)ctx->H.total_words + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
     const dim3 block(m.waves * 64);
 
     // The walk descends into the refracted child directly and parks the reflected one:

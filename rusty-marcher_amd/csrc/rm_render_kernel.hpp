@@ -57,6 +57,10 @@ struct StackEntry {
     uint32_t depth, _pad;
 };
 
+// Per-wave LDS block behind the scene copy: level 0 of the ray stack (7 f64 columns + one
+// u32 column of 64 lanes) during the walk, then the transpose slab of the stores.
+#define RM_WAVE_LDS_WORDS (64u * 7u + 32u)
+
 extern __shared__ double rm_lds[];
 
 // Every workgroup keeps its own copy of the scene in LDS; all later reads are
