@@ -122,6 +122,7 @@ struct rm_ctx {
     // reference's scenes (ground, objects resting on it) go first and the cheap sky rows
     // drain (1080p demo: 124 -> 116 us; hashed order 131 us).
     int tile_order = TILE_ORDER_REVERSE;
+    bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
 
     // device framebuffer of rm_render
@@ -148,8 +149,14 @@ static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
             return ctx_fail(ctx, RM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
-// Scene blob + output slabs must fit beside at least one other workgroup.
-static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 64 * 1024;
+// Scenes up to this size get a copy in every workgroup's LDS for the per-lane gathers;
+// larger ones are read from global memory only (the primitive loops always are, through
+// scalar loads).  Measured: the LDS copy is worth 2 % on the 1.3 KB demo scene (81.3 vs
+// 82.8 us), nothing on the 7.6 KB cornell box (153 vs 150 us) and costs 20 % on the 29 KB
+// synthetic scene (10.5 vs 8.7 ms: every workgroup re-stages the blob).
+// RM_ERR_SCENE_LIMIT is left for what the blob's 32-bit word offsets cannot address.
+static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 4 * 1024;
+static constexpr uint64_t RM_SCENE_MAX_WORDS = 0xFFFFFFF0ull;
 
 // Kernel instantiation table: stack depth x pow flavour for one launch geometry.
 template <int W, int T>
@@ -161,6 +168,21 @@ static const void *pick_static(int stack, int pow_mode, bool fast) {
                                            : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, T>;  \
         return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, T>     \
                                        : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, T>;    \
+    }
+    RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
+#undef RM_ROW
+    return nullptr;
+}
+
+// the same table for the unstaged kernel (scene blob read from global memory only)
+static const void *pick_unstaged(int stack, int pow_mode, bool fast) {
+#define RM_ROW(S)                                                                                    \
+    if (stack == S) {                                                                                \
+        if (fast)                                                                                    \
+            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, 4, 1, false>   \
+                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, 4, 1, false>;  \
+        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, 4, 1, false>     \
+                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, 4, 1, false>;    \
     }
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
@@ -208,6 +230,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if ((e = hipMalloc(&ctx->d_max, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if (const char *env = std::getenv("RM_FORCE_GENERIC_POW")) ctx->force_generic_pow = env[0] == '1';
     if (const char *env = std::getenv("RM_FORCE_STRICT_FP")) ctx->force_strict_fp = env[0] == '1';
+    if (const char *env = std::getenv("RM_FORCE_UNSTAGED")) ctx->force_unstaged = env[0] == '1';
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -303,6 +326,12 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     }
     H.max_polygon_vertices = max_nv;
 
+    // 32-bit word offsets: refuse scenes they cannot address
+    const uint64_t need_words = (uint64_t)H.n_spheres * RM_SPHERE_WORDS + (uint64_t)H.n_polygons * RM_POLYGON_WORDS +
+                                ((uint64_t)n_pverts + 1u) * RM_PVERT_WORDS + (uint64_t)H.n_triangles * RM_TRIANGLE_WORDS +
+                                (uint64_t)H.n_prims * (RM_MATERIAL_WORDS + 1u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS + 64u;
+    if (need_words > RM_SCENE_MAX_WORDS)
+        return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, "rm_scene_upload: scene exceeds the 32 GiB the device layout can address");
     uint32_t off = 0;
     auto take = [&](uint32_t words) { uint32_t o = off; off += (words + 1u) & ~1u; return o; };
     H.off_spheres = take(H.n_spheres * RM_SPHERE_WORDS);
@@ -313,15 +342,6 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
     H.off_keys = take((H.n_prims + 1u) / 2u);
     H.total_words = off;
-
-    const size_t blob_bytes = (size_t)H.total_words * sizeof(double);
-    if (blob_bytes > RM_LDS_SCENE_LIMIT_BYTES) {
-        char msg[200];
-        std::snprintf(msg, sizeof msg,
-                      "rm_scene_upload: scene needs %zu B of LDS, limit is %zu B (%u primitives, %u lights)", blob_bytes,
-                      RM_LDS_SCENE_LIMIT_BYTES, H.n_prims, H.n_lights);
-        return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, msg);
-    }
 
     std::vector<double> blob(H.total_words ? H.total_words : 2, 0.);
     auto put_material = [&](uint32_t pid, const rm_reflectance &r) {
@@ -461,8 +481,10 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     // launch geometry: one tile per wave; small scenes get one wave per workgroup,
     // larger ones share the LDS copy of the scene between four waves
     rm_launch_mode m = ctx->mode;
-    if (m.waves == 0) { m.waves = (size_t)ctx->H.total_words * sizeof(double) <= 4096 ? 1 : 4; m.per_wave = 1; }
-    const size_t lds = ((size_t)ctx->H.total_words + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
+    const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
+    const bool staged = scene_bytes <= RM_LDS_SCENE_LIMIT_BYTES && !ctx->force_unstaged;
+    if (m.waves == 0 || !staged) { m.waves = staged ? 1 : 4; m.per_wave = 1; }
+    const size_t lds = ((staged ? (size_t)ctx->H.total_words : 0u) + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
     const dim3 block(m.waves * 64);
 
     // The walk descends into the refracted child directly and parks the reflected one:
@@ -472,7 +494,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
 
     const bool fast = !(p->flags & RM_FLAG_STRICT_FP) && !ctx->force_strict_fp;
     const void *fn = nullptr;
-    if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode, fast);
+    if (!staged) fn = pick_unstaged(stack, pow_mode, fast);
+    else if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode, fast);
     else if (m.waves == 4 && m.per_wave == 1) fn = pick_static<4, 1>(stack, pow_mode, fast);
     else if (m.waves == 1 && m.per_wave == 4) fn = pick_static<1, 4>(stack, pow_mode, fast);
     else if (m.waves == 4 && m.per_wave == 4) fn = pick_static<4, 4>(stack, pow_mode, fast);

@@ -373,13 +373,23 @@ def test_shadow_from_occluder_behind_the_light(pkg, O, ctx):
     assert lit[50, 64].sum() > gpu[50, 64].sum()      # the far sphere shadows the near one
 
 
-def test_scene_too_large_for_lds_is_reported(pkg, ctx):
-    s = pkg.Scene.new()
-    tri = np.random.default_rng(0).uniform(-1, 1, size=(600, 9))
-    s.shapes.append(pkg.obj.Obj(tri))
-    with pytest.raises(pkg.BackendError) as e:
-        ctx.upload(s.flatten())
-    assert e.value.status == pkg._lib.RM_ERR_SCENE_LIMIT
+def test_large_scene_is_read_from_global_memory(pkg, O, ctx):
+    """Scenes beyond the LDS copy limit (4 KB) take the unstaged kernel: 700 random
+    triangles (~125 KB of scene words) + spheres, against the oracle."""
+    rng = np.random.default_rng(11)
+    base = rng.uniform(-12., 12., size=(700, 1, 3)) + np.array([0., 0., -40.])
+    tri = (base + rng.uniform(-1.5, 1.5, size=(700, 3, 3))).reshape(700, 9)
+    s, so = pkg.Scene.new(), O.OracleScene()
+    s.shapes.append(pkg.obj.Obj(tri)); so.add_obj(tri)
+    glass = dict(diffusion=0.4, diffuse_color=(0.8, 0.9, 0.7), specular=0.8, specular_exponent=40.,
+                 is_glass_like=True, reflection=0.35, refractive_index=1.4)
+    s.shapes.append(pkg.sphere.create(pkg.Vec3f(0., 0., -15.), 4., pkg.Reflectance(**glass)))
+    so.add_sphere((0., 0., -15.), 4., O.reflectance(**glass))
+    for pos, col, inten in workloads.DEMO_LIGHTS:
+        s.lights.append(pkg.create_light(pkg.Vec3f(*pos), pkg.Vec3f(*col), inten)); so.add_light(pos, col, inten)
+    gpu, _ = gpu_render(pkg, ctx, s, 192, 128, 6)
+    compare(gpu, O.render(so, 192, 128, max_depth=6))
+    assert (gpu.sum(axis=2) > 0).mean() > 0.03               # half the random triangles wind clockwise
     ctx.upload(pkg.Scene.create_default().flatten())         # context stays usable
 
 
