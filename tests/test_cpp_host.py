@@ -1,0 +1,68 @@
+"""The C++ host mirror (rusty-marcher_amd/host/rusty_marcher.hpp) and its command-line
+harness rm_demo: the reference's UI flow main.rs:119-123, 261-327, 329-357 (default scene /
+open .obj -> render -> normalize -> write_ppm) over the C ABI, from compiled code."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def rm_demo(entry):
+    exe = os.path.join(entry.PKG_DIR, "lib", "rm_demo")
+    if not os.path.exists(exe):
+        entry.build()
+    assert os.path.exists(exe)
+    return exe
+
+
+def test_dump_default_scene_matches_library(pkg, rm_demo):
+    out = subprocess.check_output([rm_demo, "--dump-scene"]).decode().splitlines()
+    d = pkg.Scene.create_default().flatten().desc()
+    assert out[0].startswith("shapes 6 spheres 4 polygons 2 polygon_vertices 7 triangles 0 lights 2")
+    for i in range(4):
+        s = d.spheres[i]
+        assert out[1 + i] == "sphere %d c %.17g %.17g %.17g r2 %.17g glass %d exp %.17g" % (
+            i, s.center.x, s.center.y, s.center.z, s.radius_square, s.reflectance.is_glass_like,
+            s.reflectance.specular_exponent)
+    light = [l for l in out if l.startswith("light 1")][0]
+    assert light == "light 1 p 20 20 20 c 1 0.5 0.5 i 0.80000000000000004"
+
+
+def test_dump_obj_scene_and_camera(rm_demo, cornell_path):
+    out = subprocess.check_output([rm_demo, "--obj", cornell_path, "--camera", "0,5,-5", "--dump-scene"]).decode()
+    assert out.splitlines()[0] == ("shapes 8 spheres 0 polygons 0 polygon_vertices 0 triangles 36 lights 2 "
+                                   "camera 0 5 -5")
+
+
+def test_failure_is_a_panic_exit(rm_demo, tmp_path):
+    import torch
+    r = subprocess.run([rm_demo, "--obj", str(tmp_path / "broken.obj"), "--dump-scene"], capture_output=True)
+    assert r.returncode == 0                      # obj::load -> None: empty scene, two lights (main.rs:276)
+    assert b"shapes 0" in r.stdout
+    (tmp_path / "nomtl.obj").write_text("mtllib nothere.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    r = subprocess.run([rm_demo, "--obj", str(tmp_path / "nomtl.obj"), "--dump-scene"], capture_output=True)
+    assert r.returncode == 101 and b"WOOPS" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([rm_demo, "--width", "64", "--height", "64"], capture_output=True)
+        assert r.returncode == 101 and b"no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--strict"]])
+def test_rm_demo_reproduces_out_ppm(rm_demo, golden_ppm, tmp_path, extra):
+    out = tmp_path / "out.ppm"
+    log = subprocess.check_output([rm_demo, "--out", str(out)] + extra).decode()
+    assert "Rendering using patches of size 32, using 450 patches overall" in log
+    assert "Dimensions mismatch" in log and "Scene rendered in " in log
+    data = out.read_bytes()
+    assert len(data) == len(golden_ppm) and data[:15] == golden_ppm[:15]
+    n_diff = int((np.frombuffer(data, np.uint8) != np.frombuffer(golden_ppm, np.uint8)).sum())
+    assert n_diff <= 2, "%d bytes differ from the reference's out.ppm" % n_diff
+
+
+@pytest.mark.gpu
+def test_rm_demo_width_panic(rm_demo, tmp_path):
+    r = subprocess.run([rm_demo, "--width", "100", "--height", "64", "--out", str(tmp_path / "x.ppm")], capture_output=True)
+    assert r.returncode == 101 and b"multiple of 32" in r.stderr
