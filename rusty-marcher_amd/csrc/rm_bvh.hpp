@@ -1,0 +1,101 @@
+// rm_bvh.hpp -- host-side builder of the bounding-volume hierarchy the kernel walks for
+// scenes with many spheres / mesh triangles (the reference computes a
+// BoundingBox per shape, shapes.rs:34-86, and never consults it).
+//
+// The hierarchy only decides WHICH primitives a wave tests; the tests themselves, the
+// closest-hit ordering and the list-order tie-break are unchanged, so results are
+// identical to the brute-force walk.  Boxes are inflated by a relative margin so that
+// rounding in the kernel's slab test can never cull a primitive the exact test would hit.
+//
+// Node (16 words): left child box min xyz, max xyz | right child box min xyz, max xyz |
+// left ref | right ref | 2 pad.  A ref is a u64: low 32 bits = node index (inner) or
+// first primitive (leaf), high 32 bits = 0 (inner) or the leaf's primitive count.
+#ifndef RM_BVH_HPP
+#define RM_BVH_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#define RM_BVH_NODE_WORDS 16u
+
+struct rm_aabb {
+    double lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<double>::infinity(); hi[a] = -lo[a]; }
+    }
+    void grow(const rm_aabb &o) {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], o.lo[a]); hi[a] = std::max(hi[a], o.hi[a]); }
+    }
+    double centre(int a) const { return 0.5 * (lo[a] + hi[a]); }
+};
+
+struct rm_bvh {
+    std::vector<double> nodes;        // RM_BVH_NODE_WORDS per node, node 0 is the root
+    std::vector<uint32_t> order;      // order[k] = index (into the input boxes) of the k-th primitive after reordering
+};
+
+namespace rm_bvh_detail {
+
+inline void inflate(rm_aabb &b) {
+    for (int a = 0; a < 3; a++) {
+        const double m = 1e-7 * (std::fabs(b.lo[a]) + std::fabs(b.hi[a]) + (b.hi[a] - b.lo[a])) + 1e-9;
+        b.lo[a] -= m;
+        b.hi[a] += m;
+    }
+}
+
+struct Builder {
+    const std::vector<rm_aabb> &boxes;
+    uint32_t leaf_size;
+    rm_bvh &out;
+
+    // Builds the subtree over order[first, first+count); returns its ref and box.
+    uint64_t build(uint32_t first, uint32_t count, rm_aabb &box) {
+        box.reset();
+        for (uint32_t k = 0; k < count; k++) box.grow(boxes[out.order[first + k]]);
+        if (count <= leaf_size) return ((uint64_t)count << 32) | first;           // leaf
+        rm_aabb cb;
+        cb.reset();
+        for (uint32_t k = 0; k < count; k++) {
+            const rm_aabb &b = boxes[out.order[first + k]];
+            for (int a = 0; a < 3; a++) { cb.lo[a] = std::min(cb.lo[a], b.centre(a)); cb.hi[a] = std::max(cb.hi[a], b.centre(a)); }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; a++) if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+        const uint32_t half = count / 2;
+        std::nth_element(out.order.begin() + first, out.order.begin() + first + half, out.order.begin() + first + count,
+                         [&](uint32_t x, uint32_t y) { return boxes[x].centre(axis) < boxes[y].centre(axis); });
+        const uint32_t me = (uint32_t)(out.nodes.size() / RM_BVH_NODE_WORDS);
+        out.nodes.resize(out.nodes.size() + RM_BVH_NODE_WORDS, 0.);
+        rm_aabb lb, rb;
+        const uint64_t lref = build(first, half, lb);
+        const uint64_t rref = build(first + half, count - half, rb);
+        inflate(lb);
+        inflate(rb);
+        double *n = &out.nodes[(size_t)me * RM_BVH_NODE_WORDS];
+        for (int a = 0; a < 3; a++) { n[a] = lb.lo[a]; n[3 + a] = lb.hi[a]; n[6 + a] = rb.lo[a]; n[9 + a] = rb.hi[a]; }
+        std::memcpy(&n[12], &lref, 8);
+        std::memcpy(&n[13], &rref, 8);
+        return me;                                                                // inner: high word 0
+    }
+};
+
+}  // namespace rm_bvh_detail
+
+// Builds a hierarchy over `boxes` with at most `leaf_size` primitives per leaf.  The root
+// (node 0) is always an inner node: needs at least leaf_size + 1 primitives.
+inline rm_bvh rm_build_bvh(const std::vector<rm_aabb> &boxes, uint32_t leaf_size) {
+    rm_bvh out;
+    out.order.resize(boxes.size());
+    for (uint32_t i = 0; i < boxes.size(); i++) out.order[i] = i;
+    rm_bvh_detail::Builder b{boxes, leaf_size, out};
+    rm_aabb root;
+    b.build(0, (uint32_t)boxes.size(), root);
+    return out;
+}
+
+#endif

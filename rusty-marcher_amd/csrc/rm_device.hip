@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "rm_bvh.hpp"
 #include "rm_internal.h"
 #include "rm_render_kernel.hpp"
 
@@ -122,6 +123,7 @@ struct rm_ctx {
     // reference's scenes (ground, objects resting on it) go first and the cheap sky rows
     // drain (1080p demo: 124 -> 116 us; hashed order 131 us).
     int tile_order = TILE_ORDER_REVERSE;
+    bool disable_bvh = false;         // RM_DISABLE_BVH=1: brute-force walk (A/B knob)
     bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
 
@@ -157,6 +159,9 @@ static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
 // RM_ERR_SCENE_LIMIT is left for what the blob's 32-bit word offsets cannot address.
 static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 4 * 1024;
 static constexpr uint64_t RM_SCENE_MAX_WORDS = 0xFFFFFFF0ull;
+// A hierarchy is built over a kind once it has this many primitives (below, the flat walk
+// is as fast: the demo scene has 4 spheres).
+static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 
 // Kernel instantiation table: stack depth x pow flavour for one launch geometry.
 template <int W, int T>
@@ -174,20 +179,23 @@ static const void *pick_static(int stack, int pow_mode, bool fast) {
     return nullptr;
 }
 
-// the same table for the unstaged kernel (scene blob read from global memory only)
+// the same table for the unstaged kernels (scene blob read from global memory only),
+// without and with the wave-cooperative hierarchy walk
+template <bool BVH>
 static const void *pick_unstaged(int stack, int pow_mode, bool fast) {
 #define RM_ROW(S)                                                                                    \
     if (stack == S) {                                                                                \
         if (fast)                                                                                    \
-            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, 4, 1, false>   \
-                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, 4, 1, false>;  \
-        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, 4, 1, false>     \
-                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, 4, 1, false>;    \
+            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, 4, 1, false, BVH>   \
+                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, 4, 1, false, BVH>;  \
+        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, 4, 1, false, BVH>     \
+                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, 4, 1, false, BVH>;    \
     }
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
     return nullptr;
 }
+
 extern "C" {
 
 const char *rm_build_info(void) {
@@ -231,6 +239,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FORCE_GENERIC_POW")) ctx->force_generic_pow = env[0] == '1';
     if (const char *env = std::getenv("RM_FORCE_STRICT_FP")) ctx->force_strict_fp = env[0] == '1';
     if (const char *env = std::getenv("RM_FORCE_UNSTAGED")) ctx->force_unstaged = env[0] == '1';
+    if (const char *env = std::getenv("RM_DISABLE_BVH")) ctx->disable_bvh = env[0] == '1';
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -301,6 +310,41 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
             return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: unknown shape kind");
         }
     }
+    // ---- hierarchies over the spheres and the mesh triangles (rm_bvh.hpp): primitives of
+    // a kind are re-ordered into leaf order; their list-order keys travel with them
+    rm_bvh bvh_s, bvh_t;
+    const bool use_bvh = !ctx->disable_bvh;
+    if (use_bvh && sphere_src.size() >= RM_BVH_MIN_SPHERES) {
+        std::vector<rm_aabb> boxes(sphere_src.size());
+        for (size_t i = 0; i < sphere_src.size(); i++) {
+            const rm_sphere &sp = d->spheres[sphere_src[i]];
+            const double r = std::sqrt(sp.radius_square) * (1. + 1e-12);
+            const double c[3] = {sp.center.x, sp.center.y, sp.center.z};
+            for (int a = 0; a < 3; a++) { boxes[i].lo[a] = c[a] - r; boxes[i].hi[a] = c[a] + r; }
+        }
+        bvh_s = rm_build_bvh(boxes, 4);
+        std::vector<uint32_t> src(sphere_src.size()), key(sphere_src.size());
+        for (size_t k = 0; k < src.size(); k++) { src[k] = sphere_src[bvh_s.order[k]]; key[k] = sphere_key[bvh_s.order[k]]; }
+        sphere_src.swap(src);
+        sphere_key.swap(key);
+    }
+    if (use_bvh && tri_src.size() >= RM_BVH_MIN_TRIANGLES) {
+        std::vector<rm_aabb> boxes(tri_src.size());
+        for (size_t i = 0; i < tri_src.size(); i++) {
+            const rm_triangle &t = d->triangles[tri_src[i]];
+            boxes[i].reset();
+            for (const rm_vec3 &v : t.vertices) {
+                const double c[3] = {v.x, v.y, v.z};
+                for (int a = 0; a < 3; a++) { boxes[i].lo[a] = std::min(boxes[i].lo[a], c[a]); boxes[i].hi[a] = std::max(boxes[i].hi[a], c[a]); }
+            }
+        }
+        bvh_t = rm_build_bvh(boxes, 2);
+        std::vector<uint32_t> src(tri_src.size()), key(tri_src.size());
+        for (size_t k = 0; k < src.size(); k++) { src[k] = tri_src[bvh_t.order[k]]; key[k] = tri_key[bvh_t.order[k]]; }
+        tri_src.swap(src);
+        tri_key.swap(key);
+    }
+
     std::vector<uint32_t> keys;
     keys.insert(keys.end(), sphere_key.begin(), sphere_key.end());
     keys.insert(keys.end(), polygon_key.begin(), polygon_key.end());
@@ -313,23 +357,22 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.n_polygons = (uint32_t)polygon_src.size();
     H.n_triangles = (uint32_t)tri_src.size();
     H.n_lights = d->n_lights;
-    H.n_prims = H.n_spheres + H.n_polygons + H.n_triangles;
+    const uint32_t n_prims = H.n_spheres + H.n_polygons + H.n_triangles;
     H.list_ordered = ordered ? 1u : 0u;
 
-    uint32_t n_pverts = 0, max_nv = 0;
+    uint32_t n_pverts = 0;
     for (uint32_t src : polygon_src) {
         const rm_polygon &p = d->polygons[src];
         if (p.n_vertices < 3 || (uint64_t)p.first_vertex + p.n_vertices > d->n_polygon_vertices)
             return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: bad polygon vertex range");
         n_pverts += p.n_vertices;
-        if (p.n_vertices > max_nv) max_nv = p.n_vertices;
     }
-    H.max_polygon_vertices = max_nv;
 
     // 32-bit word offsets: refuse scenes they cannot address
     const uint64_t need_words = (uint64_t)H.n_spheres * RM_SPHERE_WORDS + (uint64_t)H.n_polygons * RM_POLYGON_WORDS +
                                 ((uint64_t)n_pverts + 1u) * RM_PVERT_WORDS + (uint64_t)H.n_triangles * RM_TRIANGLE_WORDS +
-                                (uint64_t)H.n_prims * (RM_MATERIAL_WORDS + 1u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS + 64u;
+                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
+                                bvh_s.nodes.size() + bvh_t.nodes.size() + 256u;
     if (need_words > RM_SCENE_MAX_WORDS)
         return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, "rm_scene_upload: scene exceeds the 32 GiB the device layout can address");
     uint32_t off = 0;
@@ -338,9 +381,12 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.off_polygons = take(H.n_polygons * RM_POLYGON_WORDS);
     H.off_pverts = take((n_pverts + 1u) * RM_PVERT_WORDS);   // +1: the loops fetch four vertices at a time
     H.off_triangles = take(H.n_triangles * RM_TRIANGLE_WORDS);
-    H.off_materials = take(H.n_prims * RM_MATERIAL_WORDS);
+    H.off_materials = take(n_prims * RM_MATERIAL_WORDS);
     H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
-    H.off_keys = take((H.n_prims + 1u) / 2u);
+    H.off_keys = take((n_prims + 1u) / 2u);
+    H.off_bvh_spheres = bvh_s.nodes.empty() ? 0u : take((uint32_t)bvh_s.nodes.size());
+    H.off_bvh_triangles = bvh_t.nodes.empty() ? 0u : take((uint32_t)bvh_t.nodes.size());
+    take(64u);                                               // batch loads may read past the last record
     H.total_words = off;
 
     std::vector<double> blob(H.total_words ? H.total_words : 2, 0.);
@@ -392,6 +438,8 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         w[6] = lt.intensity; w[7] = 0.;
     }
     if (!keys.empty()) std::memcpy(&blob[H.off_keys], keys.data(), keys.size() * sizeof(uint32_t));
+    if (H.off_bvh_spheres) std::memcpy(&blob[H.off_bvh_spheres], bvh_s.nodes.data(), bvh_s.nodes.size() * sizeof(double));
+    if (H.off_bvh_triangles) std::memcpy(&blob[H.off_bvh_triangles], bvh_t.nodes.data(), bvh_t.nodes.size() * sizeof(double));
 
     RM_HIP(ctx, hipSetDevice(ctx->device));
     RM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a render may still be reading the old blob
@@ -407,7 +455,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     ctx->have_scene = true;
     // specular_pow<POW_INTEGER> applies when pow(x, y) is a plain integer power for every material
     bool int_exp = true;
-    for (uint32_t q = 0; q < H.n_prims; q++) {
+    for (uint32_t q = 0; q < n_prims; q++) {
         const double y = blob[H.off_materials + RM_MATERIAL_WORDS * q + 5];
         int_exp = int_exp && (y >= 0. && y <= 1048576. && y == std::floor(y));
     }
@@ -482,7 +530,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     // larger ones share the LDS copy of the scene between four waves
     rm_launch_mode m = ctx->mode;
     const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
-    const bool staged = scene_bytes <= RM_LDS_SCENE_LIMIT_BYTES && !ctx->force_unstaged;
+    const bool bvh = ctx->H.off_bvh_spheres != 0 || ctx->H.off_bvh_triangles != 0;
+    const bool staged = scene_bytes <= RM_LDS_SCENE_LIMIT_BYTES && !ctx->force_unstaged && !bvh;
     if (m.waves == 0 || !staged) { m.waves = staged ? 1 : 4; m.per_wave = 1; }
     const size_t lds = ((staged ? (size_t)ctx->H.total_words : 0u) + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
     const dim3 block(m.waves * 64);
@@ -494,12 +543,10 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
 
     const bool fast = !(p->flags & RM_FLAG_STRICT_FP) && !ctx->force_strict_fp;
     const void *fn = nullptr;
-    if (!staged) fn = pick_unstaged(stack, pow_mode, fast);
+    if (!staged) fn = bvh ? pick_unstaged<true>(stack, pow_mode, fast) : pick_unstaged<false>(stack, pow_mode, fast);
     else if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode, fast);
-    else if (m.waves == 4 && m.per_wave == 1) fn = pick_static<4, 1>(stack, pow_mode, fast);
-    else if (m.waves == 1 && m.per_wave == 4) fn = pick_static<1, 4>(stack, pow_mode, fast);
-    else if (m.waves == 4 && m.per_wave == 4) fn = pick_static<4, 4>(stack, pow_mode, fast);
-    else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE");
+    else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE (this build keeps s1x1 only; "
+                                                  "the other geometries are in profiles/r01_ab_launch_modes.txt)");
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
     const dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
     if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging

@@ -28,11 +28,17 @@ const char *rm_get_host_error();
 //   lights    8 words each : px py pz  cx cy cz  intensity 0
 //   keys      1 u32 per pid (2 per word): position in Scene.shapes order, used
 //                               only to break exact distance ties (shapes.rs:130)
+//   bvh       16 words per node (rm_bvh.hpp), one hierarchy over the spheres and one
+//                               over the triangles when there are enough of them; the
+//                               primitives of a kind are then stored in leaf order
 struct rm_dev_header {
     uint32_t n_spheres, n_polygons, n_triangles, n_lights;
     uint32_t off_spheres, off_polygons, off_pverts, off_triangles;
     uint32_t off_materials, off_lights, off_keys, total_words;
-    uint32_t n_prims, list_ordered, max_polygon_vertices, _pad;
+    uint32_t list_ordered;        // grouping by kind kept Scene.shapes order (no tie keys needed)
+    uint32_t off_bvh_spheres;     // 0 = walk all spheres; else the sphere hierarchy (rm_bvh.hpp)
+    uint32_t off_bvh_triangles;   // 0 = walk all triangles; else the triangle hierarchy
+    uint32_t _pad;
 };
 
 #define RM_SPHERE_WORDS 4u

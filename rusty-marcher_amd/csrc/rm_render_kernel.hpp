@@ -19,6 +19,8 @@
 
 #include "rm_internal.h"
 
+#define RM_BVH_NODE_WORDS 16u
+
 namespace rmdev {
 
 // specular power flavours (see specular_pow in rm_trace.inc)
@@ -59,7 +61,8 @@ struct StackEntry {
 
 // Per-wave LDS block behind the scene copy: level 0 of the ray stack (7 f64 columns + one
 // u32 column of 64 lanes) during the walk, then the transpose slab of the stores.
-#define RM_WAVE_LDS_WORDS (64u * 7u + 32u)
+#define RM_WAVE_BVH_STACK_WORDS (64u * 7u + 32u)    /* the wave's hierarchy stack: 64 u32 entries */
+#define RM_WAVE_LDS_WORDS (RM_WAVE_BVH_STACK_WORDS + 32u)
 
 extern __shared__ double rm_lds[];
 

@@ -393,6 +393,35 @@ def test_large_scene_is_read_from_global_memory(pkg, O, ctx):
     ctx.upload(pkg.Scene.create_default().flatten())         # context stays usable
 
 
+def test_hierarchy_walk_equals_flat_walk_bitwise(pkg, ctx, monkeypatch):
+    """the bounding-volume hierarchy only decides WHICH primitives a wave
+    tests; the image must be bit-identical to the brute-force walk (RM_DISABLE_BVH=1),
+    including the list-order tie-break after the primitives were re-ordered into leaves."""
+    scenes = [workloads.product_scene(pkg, "synthetic256"), workloads.product_scene(pkg, "cornell")]
+    # duplicates: exact distance ties between re-ordered primitives
+    dup = pkg.Scene.new()
+    rng = np.random.default_rng(5)
+    for k in range(40):
+        c = (float(rng.uniform(-8, 8)), float(rng.uniform(-5, 5)), float(rng.uniform(-30, -12)))
+        col = tuple(float(x) for x in rng.uniform(0, 1, 3))
+        for rep in range(2):            # the same sphere twice, different colours: first in list must win
+            dup.shapes.append(pkg.sphere.create(pkg.Vec3f(*c), 1.5, pkg.Reflectance(diffuse_color=col if rep == 0 else (1., 1., 1.),
+                                                                                    is_glass_like=(k % 5 == 0), refractive_index=1.3)))
+    dup.lights.append(pkg.create_light(pkg.Vec3f(0., 10., 0.), pkg.Vec3f(1., 1., 1.), 1.))
+    scenes.append(dup)
+    monkeypatch.setenv("RM_DISABLE_BVH", "1")
+    flat_ctx = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_DISABLE_BVH")
+    try:
+        for scene in scenes:
+            a, _ = gpu_render(pkg, ctx, scene, 384, 256, 6)
+            b, _ = gpu_render(pkg, flat_ctx, scene, 384, 256, 6)
+            assert np.array_equal(a, b)
+            assert a.sum() > 0
+    finally:
+        flat_ctx.close()
+
+
 # ---------------------------------------------------------------- properties at full size
 def test_bands_tile_the_frame_bitwise(pkg, ctx):
     """Row sharding: the union of per-rank bands is bit-identical to the
