@@ -58,17 +58,31 @@ struct Builder {
         box.reset();
         for (uint32_t k = 0; k < count; k++) box.grow(boxes[out.order[first + k]]);
         if (count <= leaf_size) return ((uint64_t)count << 32) | first;           // leaf
-        rm_aabb cb;
-        cb.reset();
-        for (uint32_t k = 0; k < count; k++) {
-            const rm_aabb &b = boxes[out.order[first + k]];
-            for (int a = 0; a < 3; a++) { cb.lo[a] = std::min(cb.lo[a], b.centre(a)); cb.hi[a] = std::max(cb.hi[a], b.centre(a)); }
-        }
+        // surface-area heuristic: for each axis sort by centroid and sweep; cost(split) =
+        // area(left) * n_left + area(right) * n_right
+        auto area = [](const rm_aabb &x) {
+            const double dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        uint32_t half = count / 2;
         int axis = 0;
-        for (int a = 1; a < 3; a++) if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
-        const uint32_t half = count / 2;
-        std::nth_element(out.order.begin() + first, out.order.begin() + first + half, out.order.begin() + first + count,
-                         [&](uint32_t x, uint32_t y) { return boxes[x].centre(axis) < boxes[y].centre(axis); });
+        double best_cost = std::numeric_limits<double>::infinity();
+        std::vector<uint32_t> tmp(out.order.begin() + first, out.order.begin() + first + count), best_order;
+        std::vector<double> right_area(count);
+        for (int a = 0; a < 3; a++) {
+            std::sort(tmp.begin(), tmp.end(), [&](uint32_t x, uint32_t y) { return boxes[x].centre(a) < boxes[y].centre(a); });
+            rm_aabb acc;
+            acc.reset();
+            for (uint32_t k = count; k-- > 0;) { acc.grow(boxes[tmp[k]]); right_area[k] = area(acc); }
+            acc.reset();
+            for (uint32_t k = 1; k < count; k++) {
+                acc.grow(boxes[tmp[k - 1]]);
+                const double cost = area(acc) * k + right_area[k] * (count - k);
+                if (cost < best_cost) { best_cost = cost; half = k; axis = a; best_order = tmp; }
+            }
+        }
+        (void)axis;
+        if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), out.order.begin() + first);
         const uint32_t me = (uint32_t)(out.nodes.size() / RM_BVH_NODE_WORDS);
         out.nodes.resize(out.nodes.size() + RM_BVH_NODE_WORDS, 0.);
         rm_aabb lb, rb;

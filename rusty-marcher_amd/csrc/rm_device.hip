@@ -505,7 +505,6 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     KernelArgs a{};
     a.H = ctx->H;
     a.half_fov = p->half_fov; a.height = p->height; a.width = p->width; a.ratio = p->ratio;
-    a.inv_width = 1. / p->width; a.inv_height = 1. / p->height;
     a.cam_x = ctx->camera.x; a.cam_y = ctx->camera.y; a.cam_z = ctx->camera.z;
     a.bg_x = p->background.x; a.bg_y = p->background.y; a.bg_z = p->background.z;
     a.frame_width = p->frame_width;

@@ -39,7 +39,6 @@ static_assert(TILE_W == 8 || TILE_W == 16 || TILE_W == 32, "tile width");
 struct KernelArgs {
     rm_dev_header H;
     double half_fov, height, width, ratio;   // Renderer (renderer.rs:17-23)
-    double inv_width, inv_height;            // 1/width, 1/height (fast flavour only)
     double cam_x, cam_y, cam_z;              // Scene.camera
     double bg_x, bg_y, bg_z;                 // renderer.rs:40-44
     uint32_t frame_width;                    // FrameBuffer.width

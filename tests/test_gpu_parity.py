@@ -393,6 +393,62 @@ def test_large_scene_is_read_from_global_memory(pkg, O, ctx):
     ctx.upload(pkg.Scene.create_default().flatten())         # context stays usable
 
 
+def _icosphere_obj(path, subdivisions):
+    t = (1 + 5 ** 0.5) / 2
+    v = [np.array(p, float) / np.linalg.norm(p) for p in
+         [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+          (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdivisions):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    with open(path, "w") as o:
+        o.write("o ico\n")
+        for p in v:
+            o.write("v %.6f %.6f %.6f\n" % tuple(p * 120 + np.array([0., 0., 250.])))
+        for a, b, c in f:
+            o.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    return len(f)
+
+
+@pytest.mark.parametrize("subdivisions", [2, 4])
+def test_symmetric_mesh_keeps_the_reference_cracks(pkg, O, ctx, tmp_path, subdivisions):
+    """A mesh symmetric about x = 0 through the whole OBJ path (main.rs:261-327).  On the
+    centre column the ray's x component is exactly 0 and the edge functions of edges in the
+    plane x = 0 are exactly 0: the reference's `> 0.` (triangle.rs:13-15) makes both
+    neighbouring triangles miss -- a one-pixel crack that the kernel must reproduce in BOTH
+    flavours (an early fast flavour closed it: profiles/r01_notes_fast_flavour.txt)."""
+    from oracle import obj_oracle
+    path = str(tmp_path / "ico.obj")
+    n = _icosphere_obj(path, subdivisions)
+    assert n == 20 * 4 ** subdivisions
+    scene = pkg.Scene.open_obj(path)
+    so = O.OracleScene()
+    for _, tris in obj_oracle.load_models(path):
+        so.add_obj(np.array(tris), (0., 0., -500.))
+    for pos, col, inten in workloads.DEMO_LIGHTS:
+        so.add_light(pos, col, inten)
+    w, h = 320, 256
+    gpu, _ = gpu_render(pkg, ctx, scene, w, h, 3)
+    ref = O.render(so, w, h, max_depth=3)
+    compare(gpu, ref)
+    lit = ref.sum(axis=2) > 0
+    assert lit[:, w // 2 - 1].sum() > 50 and lit[:, w // 2 + 1].sum() > 50
+    assert lit[:, w // 2].sum() < lit[:, w // 2 - 1].sum()          # the crack exists in the reference image
+
+
 def test_hierarchy_walk_equals_flat_walk_bitwise(pkg, ctx, monkeypatch):
     """the bounding-volume hierarchy only decides WHICH primitives a wave
     tests; the image must be bit-identical to the brute-force walk (RM_DISABLE_BVH=1),
