@@ -77,7 +77,9 @@ def main():
     ap.add_argument("--payload", choices=["u8", "f64"], default="u8",
                     help="what the per-frame all-gather moves at N > 1: the display bytes (to_vec, 3 B/px) "
                          "or the f64 rows (24 B/px)")
-    ap.add_argument("--strict-fp", action="store_true", help="RM_FLAG_STRICT_FP flavour of the kernel")
+    ap.add_argument("--fast-fp", action="store_true",
+                    help="RM_FLAG_FAST_FP flavour of the kernel (FMA, Newton rsqrt): faster, but may decide "
+                         "exact-incidence pixels differently from the reference -- not the parity configuration")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the per-frame collective even at world size 1 (smoke test of the N > 1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,8 +124,8 @@ def main():
     scene = workloads.product_scene(pkg, cfg["scene"])
     ctx.upload(scene.flatten())
     params = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
-    if args.strict_fp:
-        params.flags = 1                                               # RM_FLAG_STRICT_FP
+    if args.fast_fp:
+        params.flags = 2                                               # RM_FLAG_FAST_FP
     # Per rank: the f64 frame (create_frame_buffer zero-fills; this rank's band of it is
     # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
     # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
@@ -210,11 +212,11 @@ def main():
                                                       "f64 rows stay in each rank's HBM" % args.payload)
                                       if world > 1 else ""),
                        "outputs": "f64 RGB frame [H][W][3] + u8 display frame (to_vec) per launch",
-                       "numerics": "strict" if args.strict_fp else "fast",
+                       "numerics": "fast" if args.fast_fp else "strict (the reference's operations, one rounding each)",
                        "build": L.rm_build_info().decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rmdev_fast::rm_render_static" if not args.strict_fp else "rmdev_strict::rm_render_static", "kernel_ms": kernel_ms,
+                         "kernel": "rmdev_fast::rm_render_static" if args.fast_fp else "rmdev_strict::rm_render_static", "kernel_ms": kernel_ms,
                          "bytes_per_launch": px_launch * BYTES_PER_PIXEL,
                          "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); "
                                  "achieved = 24 B x pixels written / kernel time"},

@@ -117,7 +117,7 @@ struct rm_ctx {
     rm_vec3 camera{0., 0., 0.};
     bool integer_exponents = false;   // every material's specular_exponent is a small non-negative integer
     bool force_generic_pow = false;   // RM_FORCE_GENERIC_POW=1 (A/B knob)
-    bool force_strict_fp = false;     // RM_FORCE_STRICT_FP=1 (A/B knob; same as RM_FLAG_STRICT_FP on every call)
+    bool force_fast_fp = false;       // RM_FORCE_FAST_FP=1 (A/B knob; same as RM_FLAG_FAST_FP on every call)
     // Bottom-up by default: workgroups are dispatched in id order and the drain at the end
     // of a launch runs at low occupancy, so the rows that are expensive in the
     // reference's scenes (ground, objects resting on it) go first and the cheap sky rows
@@ -237,7 +237,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc(&ctx->d_max, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if (const char *env = std::getenv("RM_FORCE_GENERIC_POW")) ctx->force_generic_pow = env[0] == '1';
-    if (const char *env = std::getenv("RM_FORCE_STRICT_FP")) ctx->force_strict_fp = env[0] == '1';
+    if (const char *env = std::getenv("RM_FORCE_FAST_FP")) ctx->force_fast_fp = env[0] == '1';
     if (const char *env = std::getenv("RM_FORCE_UNSTAGED")) ctx->force_unstaged = env[0] == '1';
     if (const char *env = std::getenv("RM_DISABLE_BVH")) ctx->disable_bvh = env[0] == '1';
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
@@ -540,7 +540,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     const int stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
     const int pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
 
-    const bool fast = !(p->flags & RM_FLAG_STRICT_FP) && !ctx->force_strict_fp;
+    const bool fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
     const void *fn = nullptr;
     if (!staged) fn = bvh ? pick_unstaged<true>(stack, pow_mode, fast) : pick_unstaged<false>(stack, pow_mode, fast);
     else if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode, fast);

@@ -3,7 +3,7 @@
 // written against the C++ host mirror (rusty_marcher.hpp).  Native harness for the C ABI.
 //
 //   rm_demo [--obj FILE] [--width W] [--height H] [--fov F] [--depth D] [--frames N]
-//           [--camera x,y,z] [--strict] [--no-normalize] [--out FILE.ppm] [--dump-scene]
+//           [--camera x,y,z] [--fast-fp] [--no-normalize] [--out FILE.ppm] [--dump-scene]
 //
 // Defaults reproduce the reference's committed engine/out.ppm: 800x600, fov 1.5, depth 3.
 #include <cstdio>
@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
     size_t width = 800, height = 600;
     double fov = 1.5;
     unsigned depth = 3, frames = 1;
-    bool strict = false, normalize = true, dump = false;
+    bool fast = false, normalize = true, dump = false;
     Vec3f cam_off;
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
@@ -54,11 +54,11 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--depth")) depth = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--frames")) frames = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--camera")) { if (std::sscanf(next(), "%lf,%lf,%lf", &cam_off.x, &cam_off.y, &cam_off.z) != 3) return 2; }
-        else if (!std::strcmp(argv[i], "--strict")) strict = true;
+        else if (!std::strcmp(argv[i], "--fast-fp")) fast = true;
         else if (!std::strcmp(argv[i], "--no-normalize")) normalize = false;
         else if (!std::strcmp(argv[i], "--out")) out = next();
         else if (!std::strcmp(argv[i], "--dump-scene")) dump = true;
-        else { std::fprintf(stderr, "usage: rm_demo [--obj FILE] [--width W] [--height H] [--fov F] [--depth D] [--frames N] [--camera x,y,z] [--strict] [--no-normalize] [--out FILE.ppm] [--dump-scene]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rm_demo [--obj FILE] [--width W] [--height H] [--fov F] [--depth D] [--frames N] [--camera x,y,z] [--fast-fp] [--no-normalize] [--out FILE.ppm] [--dump-scene]\n"); return 2; }
     }
     try {
         // main.rs:119-123 (default scene) / main.rs:261-327 (open .obj)
@@ -69,7 +69,7 @@ int main(int argc, char **argv) {
         framebuffer::FrameBuffer fb = framebuffer::create_frame_buffer(width, height);   // main.rs:240 uses 1600x1280
         renderer::Renderer r = renderer::create_renderer(fov, (double)fb.height, (double)fb.width);   // main.rs:367-368
         r.max_depth = depth;
-        if (strict) r.flags |= RM_FLAG_STRICT_FP;
+        if (fast) r.flags |= RM_FLAG_FAST_FP;
         std::string msg;
         for (unsigned f = 0; f < frames; f++) msg = r.render(fb, sc);        // main.rs:329-333
         std::printf("kernel %.3f ms, device->host %.3f ms\n", r.last_timing.kernel_ms, r.last_timing.d2h_ms);

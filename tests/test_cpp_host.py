@@ -50,7 +50,7 @@ def test_failure_is_a_panic_exit(rm_demo, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--strict"]])
+@pytest.mark.parametrize("extra", [[], ["--fast-fp"]])
 def test_rm_demo_reproduces_out_ppm(rm_demo, golden_ppm, tmp_path, extra):
     out = tmp_path / "out.ppm"
     log = subprocess.check_output([rm_demo, "--out", str(out)] + extra).decode()
