@@ -144,6 +144,7 @@ def main():
     frame8_ptr = C.c_void_p(frame8.data_ptr())
     stream_ptr = C.c_void_p(stream.cuda_stream)
     has_rows = band[1] > band[0]
+    my_chunk = gathered[rank * c_rows * 32:(rank + 1) * c_rows * 32]    # views built once: the step stays lean
 
     def step():
         """One frame: render this rank's band (f64 rows + their display bytes), then the
@@ -153,7 +154,7 @@ def main():
             if st != 0:
                 raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
         if use_dist:
-            workloads.allgather_bands(dist, gathered, rank, world)
+            dist.all_gather_into_tensor(gathered, my_chunk)              # == workloads.allgather_bands
 
     def fence():
         torch.cuda.synchronize()
