@@ -130,9 +130,14 @@ def main():
     # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
     # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
     pad_h = max(h, world * c_rows * 32)
-    frame = torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev)
-    frame8 = torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev)
-    gathered = (frame8 if args.payload == "u8" else frame)[:world * c_rows * 32]
+    # Two frames in flight at N > 1: frame k's collective runs on RCCL's stream while frame
+    # k+1 renders (double-buffered), so steady-state throughput is 1 / max(render, gather).
+    n_buf = 2 if use_dist else 1
+    frames = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
+    frames8 = [torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+    frame, frame8 = frames[0], frames8[0]
+    gathered = [(f8 if args.payload == "u8" else f)[:world * c_rows * 32] for f, f8 in zip(frames, frames8)]
+    my_chunk = [g[rank * c_rows * 32:(rank + 1) * c_rows * 32] for g in gathered]   # views built once
     # A dedicated stream: the kernel, the timing events and the RCCL op are all ordered
     # on it (torch.cuda.Event only sees the stream it is recorded on).
     stream = torch.cuda.Stream(device=dev)
@@ -140,23 +145,37 @@ def main():
     torch.cuda.set_stream(stream)
     L = pkg.lib()
     p_ref = C.byref(params)
-    frame_ptr = C.c_void_p(frame.data_ptr())
-    frame8_ptr = C.c_void_p(frame8.data_ptr())
+    frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
+    frame8_ptrs = [C.c_void_p(f.data_ptr()) for f in frames8]
     stream_ptr = C.c_void_p(stream.cuda_stream)
     has_rows = band[1] > band[0]
-    my_chunk = gathered[rank * c_rows * 32:(rank + 1) * c_rows * 32]    # views built once: the step stays lean
+    pending = [None] * n_buf
+    counter = [0]
 
     def step():
         """One frame: render this rank's band (f64 rows + their display bytes), then the
-        single collective of the frame."""
+        single collective of the frame (asynchronous: the stream is only made to wait for
+        it when its buffer is about to be rendered into again)."""
+        b = counter[0] % n_buf
+        counter[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()                      # stream-ordered; the host does not block
+            pending[b] = None
         if has_rows:
-            st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptr, frame8_ptr, stream_ptr)
+            st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], frame8_ptrs[b], stream_ptr)
             if st != 0:
                 raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
         if use_dist:
-            dist.all_gather_into_tensor(gathered, my_chunk)              # == workloads.allgather_bands
+            pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
+
+    def drain():
+        for i, wk in enumerate(pending):
+            if wk is not None:
+                wk.wait()
+                pending[i] = None
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
