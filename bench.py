@@ -209,13 +209,14 @@ def main():
     if rank == 0:
         mpx = (w * h) * args.steps / elapsed / 1e6
         achieved = px_launch * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 if pmc.get("config") == args.config and pmc.get("n_gpus", 1) == world:
                     traffic = pmc.get("hbm_bytes_per_launch")
+                    valu = {k: pmc.get(k) for k in ("valu_busy_frac", "valu_lanes_active_frac", "valu_wave_instructions")}
             except Exception:
                 traffic = None
         out = {
@@ -238,8 +239,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "rmdev_fast::rm_render_static" if args.fast_fp else "rmdev_strict::rm_render_static", "kernel_ms": kernel_ms,
                          "bytes_per_launch": px_launch * BYTES_PER_PIXEL,
-                         "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); "
-                                 "achieved = 24 B x pixels written / kernel time"},
+                         "fp64_valu": valu,
+                         "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); achieved = 24 B x pixels "
+                                 "written / kernel time; traffic and fp64_valu are PMC figures of the same command "
+                                 "(profiles/pmc_latest.json), not measured in this run"},
         }
         if args.check:
             O = G.load_oracle()
