@@ -27,6 +27,10 @@ CONFIGS = {
     "C3": dict(scene="cornell", width=1920, height=1080, max_depth=5),
     "C4": dict(scene="demo", width=7680, height=4320, max_depth=8),
     "C5": dict(scene="synthetic256", width=4096, height=4096, max_depth=10),
+    # the reference's own operating points (depth cap 3, renderer.rs:262)
+    "REF800": dict(scene="demo", width=800, height=600, max_depth=3),      # engine/out.ppm
+    "UI": dict(scene="demo", width=1600, height=1280, max_depth=3),        # main.rs:240 framebuffer
+    "SHOT": dict(scene="demo", width=1280, height=800, max_depth=3),       # README screenshot: 92 ms, 11.13 MP/s
 }
 
 
