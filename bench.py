@@ -105,27 +105,47 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    # (RM_BENCH_BACKEND=gloo with every rank on GPU 0 is a dry run of the N > 1 code path on
+    # a one-GPU box; the real thing is one GPU per rank over RCCL)
+    backend = os.environ.get("RM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = G.load_package()
     cfg = workloads.CONFIGS[args.config]
     w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
     n_rows = h // 32
-    c_rows, bands = workloads.equal_bands(n_rows, world)
-    band = bands[rank]
+    # N > 1, u8 payload: cyclic row ownership (rank r renders patch rows r, r+N, ...: every
+    # rank gets its share of cheap sky and expensive ground rows) with the display bytes
+    # packed per rank; f64 payload: contiguous equal bands gathered in place.
+    cyclic = world > 1 and args.payload == "u8"
+    if cyclic:
+        c_rows, owned = workloads.cyclic_rows(n_rows, world)
+        band = (rank, n_rows, world)
+        n_owned = len(owned[rank])
+    else:
+        c_rows, bands = workloads.equal_bands(n_rows, world)
+        band = bands[rank]
+        n_owned = band[1] - band[0]
 
     ctx = pkg.backend.Context(local_rank)
     scene = workloads.product_scene(pkg, cfg["scene"])
     ctx.upload(scene.flatten())
     params = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
     if args.fast_fp:
-        params.flags = 2                                               # RM_FLAG_FAST_FP
+        params.flags |= 2                                              # RM_FLAG_FAST_FP
+    if cyclic:
+        params.flags |= 4                                              # RM_FLAG_U8_COMPACT
     # Per rank: the f64 frame (create_frame_buffer zero-fills; this rank's band of it is
     # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
     # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
@@ -146,9 +166,11 @@ def main():
     L = pkg.lib()
     p_ref = C.byref(params)
     frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
-    frame8_ptrs = [C.c_void_p(f.data_ptr()) for f in frames8]
+    # cyclic: the kernel packs this rank's display rows straight into its chunk of the gather buffer
+    frame8_ptrs = [C.c_void_p((ch if cyclic else f8).data_ptr()) for ch, f8 in zip(my_chunk, frames8)]
+    display = torch.zeros_like(gathered[0]) if cyclic and rank == 0 else None   # image-order frame at the consumer
     stream_ptr = C.c_void_p(stream.cuda_stream)
-    has_rows = band[1] > band[0]
+    has_rows = n_owned > 0
     pending = [None] * n_buf
     counter = [0]
 
@@ -161,6 +183,8 @@ def main():
         if pending[b] is not None:
             pending[b].wait()                      # stream-ordered; the host does not block
             pending[b] = None
+            if display is not None:
+                workloads.deinterleave_rows(gathered[b], world, display)
         if has_rows:
             st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], frame8_ptrs[b], stream_ptr)
             if st != 0:
@@ -173,6 +197,8 @@ def main():
             if wk is not None:
                 wk.wait()
                 pending[i] = None
+                if display is not None:
+                    workloads.deinterleave_rows(gathered[i], world, display)
 
     def fence():
         drain()
@@ -204,7 +230,7 @@ def main():
     # N > 1 the gather's stream time is inside the bracket too, so it is only reported
     # as the kernel's duration at N = 1)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    px_launch = (band[1] - band[0]) * 32 * w                            # pixels one launch writes
+    px_launch = n_owned * 32 * w                                        # pixels one launch writes
 
     if rank == 0:
         mpx = (w * h) * args.steps / elapsed / 1e6
@@ -228,8 +254,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s scene %dx%d, depth cap %d, fov 1.5, device-resident f64 RGB frame"
                                    % (args.config, cfg["scene"], w, h, depth),
-                       "sharding": "row bands of %d patch rows (32 px) per rank, %d rank(s)%s"
-                                   % (c_rows, world, (", one in-place RCCL all-gather of the %s rows per frame; "
+                       "sharding": "%s of %d patch rows (32 px) per rank, %d rank(s)%s"
+                                   % ("cyclic rows (r, r+N, ...)" if cyclic else "contiguous bands", c_rows, world, (", one in-place RCCL all-gather of the %s rows per frame; "
                                                       "f64 rows stay in each rank's HBM" % args.payload)
                                       if world > 1 else ""),
                        "outputs": "f64 RGB frame [H][W][3] + u8 display frame (to_vec) per launch",
@@ -247,10 +273,14 @@ def main():
         if args.check:
             O = G.load_oracle()
             ref = O.render(workloads.oracle_scene(O, cfg["scene"]), w, h, max_depth=depth)
-            got = frame[:h].cpu().numpy()
-            out["max_abs_delta_vs_oracle"] = float(np.abs(got[:n_rows * 32] - ref[:n_rows * 32]).max()) if world == 1 else None
-            u8 = frame8[:n_rows * 32].cpu().numpy().reshape(-1)
-            out["display_bytes_differing_from_oracle"] = int((u8 != O.to_vec(ref[:n_rows * 32].copy())).sum())
+            # what rank 0 holds after the last frame: the whole f64 frame (N = 1, or f64
+            # payload), and / or the whole display frame (N = 1, or u8 payload)
+            if world == 1 or args.payload == "f64":
+                got = frame[:n_rows * 32].cpu().numpy()
+                out["max_abs_delta_vs_oracle"] = float(np.abs(got - ref[:n_rows * 32]).max())
+            if world == 1 or args.payload == "u8":
+                u8 = (display if display is not None else frame8)[:n_rows * 32].cpu().numpy().reshape(-1)
+                out["display_bytes_differing_from_oracle"] = int((u8 != O.to_vec(ref[:n_rows * 32].copy())).sum())
         if world == 1 and not args.no_cpu_baseline:
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, cfg)

@@ -119,11 +119,13 @@ typedef struct rm_params {
     uint32_t patch_size;
     /* renderer.rs:40-44 (reference: 0.1, 0.1, 0.1) */
     rm_vec3 background;
-    /* Row band owned by this caller, in patch rows: [begin, end).  end == 0 means
-     * "all frame_height/32 patch rows".  Pixels outside the band are untouched. */
+    /* Patch rows owned by this caller: begin, begin + stride, begin + 2 stride, ... < end.
+     * end == 0 means "frame_height/32"; stride 0 or 1 means every row of [begin, end).
+     * A stride of N with begin = rank deals the rows out cyclically to N GPUs (sky rows
+     * are cheap, ground rows expensive).  Pixels of rows not owned are untouched. */
     uint32_t patch_row_begin, patch_row_end;
     uint32_t flags;        /* RM_FLAG_* */
-    uint32_t _pad;
+    uint32_t patch_row_stride;
 } rm_params;
 
 #define RM_FLAG_NONE 0u
@@ -137,6 +139,10 @@ typedef struct rm_params {
  * reference ONLY at such exact-incidence pixels (the demo scene has a handful per frame
  * for some camera positions: its triangle has small-integer coordinates). */
 #define RM_FLAG_FAST_FP 2u
+/* rm_render_device_u8 only: device_rgb8 holds just the OWNED patch rows, packed -- the
+ * k-th owned patch row occupies byte rows [32k, 32k + 32) of a [n_owned*32][frame_width][3]
+ * buffer -- so that a rank's display bytes are one contiguous chunk for a gather. */
+#define RM_FLAG_U8_COMPACT 4u
 
 typedef struct rm_timing {
     double kernel_ms;   /* HIP-event time of the render kernel on its stream */

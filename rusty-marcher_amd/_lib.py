@@ -67,7 +67,7 @@ class rm_params(C.Structure):
                 ("max_depth", C.c_uint32), ("patch_size", C.c_uint32),
                 ("background", rm_vec3),
                 ("patch_row_begin", C.c_uint32), ("patch_row_end", C.c_uint32),
-                ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+                ("flags", C.c_uint32), ("patch_row_stride", C.c_uint32)]
 
 
 class rm_timing(C.Structure):

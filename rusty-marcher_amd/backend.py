@@ -71,4 +71,6 @@ def make_params(fov, height, width, max_depth=3, band=None):
     p.max_depth = int(max_depth)
     if band is not None:
         p.patch_row_begin, p.patch_row_end = int(band[0]), int(band[1])
+        if len(band) > 2:
+            p.patch_row_stride = int(band[2])
     return p

@@ -470,8 +470,14 @@ rm_status rm_camera_update(rm_ctx *ctx, rm_vec3 camera) {
     return RM_OK;
 }
 
-// Validates params and computes the band; shared by both render entry points.
-static rm_status check_params(rm_ctx *ctx, const rm_params *p, uint32_t *row_begin, uint32_t *row_end) {
+// The patch rows a call owns: begin, begin + stride, ... < end.
+struct rm_band {
+    uint32_t begin = 0, end = 0, stride = 1;
+    uint32_t count() const { return end > begin ? (end - begin + stride - 1) / stride : 0; }
+};
+
+// Validates params and computes the band; shared by the render entry points.
+static rm_status check_params(rm_ctx *ctx, const rm_params *p, rm_band *band) {
     if (!p) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: NULL params");
     if (!ctx->have_scene) return ctx_fail(ctx, RM_ERR_NO_SCENE, "render: no scene uploaded (rm_scene_upload)");
     if (p->patch_size != RM_PATCH_SIZE) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: patch_size must be 32 (renderer.rs:47)");
@@ -485,21 +491,28 @@ static rm_status check_params(rm_ctx *ctx, const rm_params *p, uint32_t *row_beg
     uint32_t b = p->patch_row_begin, e = p->patch_row_end == 0 ? n_height : p->patch_row_end;
     if (e > n_height) e = n_height;
     if (b > e) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: patch_row_begin > patch_row_end");
-    *row_begin = b;
-    *row_end = e;
+    band->begin = b;
+    band->end = e;
+    band->stride = p->patch_row_stride == 0 ? 1u : p->patch_row_stride;
     return RM_OK;
 }
 
-static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_begin, uint32_t row_end, double *d_frame,
+static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &band, double *d_frame,
                                uint8_t *d_frame8, hipStream_t stream) {
-    if (row_begin == row_end) return RM_OK;
+    const uint32_t n_rows = band.count();
+    if (n_rows == 0) return RM_OK;
+    const uint32_t row_begin = band.begin;
     const uint32_t n_width = p->frame_width / RM_PATCH_SIZE;
     if (p->max_depth == 0) {
-        const size_t first_px = (size_t)row_begin * 32u * p->frame_width;
-        const size_t n_px = (size_t)(row_end - row_begin) * 32u * p->frame_width;
-        hipLaunchKernelGGL(rm_fill_band_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, d_frame,
-                           first_px, n_px, p->background.x, p->background.y, p->background.z);
-        RM_HIP(ctx, hipGetLastError());
+        // one fill per run of consecutive owned rows (a single run unless the band is strided)
+        const uint32_t run = band.stride == 1 ? n_rows : 1u;
+        for (uint32_t k = 0; k < n_rows; k += run) {
+            const size_t first_px = (size_t)(row_begin + k * band.stride) * 32u * p->frame_width;
+            const size_t n_px = (size_t)run * 32u * p->frame_width;
+            hipLaunchKernelGGL(rm_fill_band_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, d_frame,
+                               first_px, n_px, p->background.x, p->background.y, p->background.z);
+            RM_HIP(ctx, hipGetLastError());
+        }
         return RM_OK;
     }
     KernelArgs a{};
@@ -509,9 +522,11 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
     a.bg_x = p->background.x; a.bg_y = p->background.y; a.bg_z = p->background.z;
     a.frame_width = p->frame_width;
     a.patch_row_begin = row_begin;
+    a.patch_row_stride = band.stride;
+    a.u8_compact = (p->flags & RM_FLAG_U8_COMPACT) ? 1u : 0u;
     a.max_depth = p->max_depth;
     a.n_width = n_width;
-    a.n_tiles = (row_end - row_begin) * n_width * 16u;
+    a.n_tiles = n_rows * n_width * 16u;
     a.debug_stamps = nullptr;
     a.frame8 = d_frame8;
     // dispatch order: tile = (id * order_mul + order_add) % n_tiles, a bijection
@@ -573,32 +588,32 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, uint32_t row_beg
 rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render_device: NULL ctx");
     if (!device_rgb) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render_device: NULL device buffer");
-    uint32_t b = 0, e = 0;
-    rm_status st = check_params(ctx, params, &b, &e);
+    rm_band band;
+    rm_status st = check_params(ctx, params, &band);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)hip_stream;   // NULL is HIP's default stream, as in any HIP API
-    return launch_render(ctx, params, b, e, (double *)device_rgb, nullptr, s);
+    return launch_render(ctx, params, band, (double *)device_rgb, nullptr, s);
 }
 
 rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
                               void *hip_stream) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render_device_u8: NULL ctx");
     if (!device_rgb || !device_rgb8) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render_device_u8: NULL device buffer");
-    uint32_t b = 0, e = 0;
-    rm_status st = check_params(ctx, params, &b, &e);
+    rm_band band;
+    rm_status st = check_params(ctx, params, &band);
     if (st != RM_OK) return st;
     if (params->max_depth == 0)
         return ctx_fail(ctx, RM_ERR_DEPTH, "rm_render_device_u8: max_depth 0 renders no ray; use rm_render_device + rm_postprocess");
     RM_HIP(ctx, hipSetDevice(ctx->device));
-    return launch_render(ctx, params, b, e, (double *)device_rgb, (uint8_t *)device_rgb8, (hipStream_t)hip_stream);
+    return launch_render(ctx, params, band, (double *)device_rgb, (uint8_t *)device_rgb8, (hipStream_t)hip_stream);
 }
 
 rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render: NULL ctx");
     const auto t_begin = std::chrono::steady_clock::now();
-    uint32_t b = 0, e = 0;
-    rm_status st = check_params(ctx, params, &b, &e);
+    rm_band band;
+    rm_status st = check_params(ctx, params, &band);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipSetDevice(ctx->device));
 
@@ -617,20 +632,23 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     }
 
     RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    st = launch_render(ctx, params, b, e, ctx->d_frame, nullptr, ctx->stream);
+    st = launch_render(ctx, params, band, ctx->d_frame, nullptr, ctx->stream);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     double d2h_ms = 0.;
-    if (host_rgb && e > b) {
-        // Only the band's rows are copied: rows below the last whole patch row keep the
+    if (host_rgb && band.count() > 0) {
+        // Only the owned rows are copied: rows below the last whole patch row keep the
         // caller's previous contents, as in the reference (renderer.rs:53).
         const size_t row_bytes = (size_t)params->frame_width * 3u * sizeof(double);
-        const size_t off = (size_t)b * 32u * row_bytes;
-        const size_t len = (size_t)(e - b) * 32u * row_bytes;
         RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const auto t0 = std::chrono::steady_clock::now();
-        RM_HIP(ctx, hipMemcpy((char *)host_rgb + off, (const char *)ctx->d_frame + off, len, hipMemcpyDeviceToHost));
+        const uint32_t run = band.stride == 1 ? band.count() : 1u;     // consecutive owned patch rows per copy
+        for (uint32_t k = 0; k < band.count(); k += run) {
+            const size_t off = (size_t)(band.begin + k * band.stride) * 32u * row_bytes;
+            RM_HIP(ctx, hipMemcpy((char *)host_rgb + off, (const char *)ctx->d_frame + off, (size_t)run * 32u * row_bytes,
+                                  hipMemcpyDeviceToHost));
+        }
         d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     } else {
         RM_HIP(ctx, hipStreamSynchronize(ctx->stream));

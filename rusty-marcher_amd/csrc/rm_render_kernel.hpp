@@ -42,7 +42,9 @@ struct KernelArgs {
     double cam_x, cam_y, cam_z;              // Scene.camera
     double bg_x, bg_y, bg_z;                 // renderer.rs:40-44
     uint32_t frame_width;                    // FrameBuffer.width
-    uint32_t patch_row_begin;                // first patch row of the band
+    uint32_t patch_row_begin;                // first owned patch row
+    uint32_t patch_row_stride;               // owned rows: begin, begin + stride, ...
+    uint32_t u8_compact;                     // RM_FLAG_U8_COMPACT: frame8 holds only the owned rows, packed
     uint32_t max_depth;                      // renderer.rs:262
     uint32_t n_width;                        // patches per row, renderer.rs:54
     uint32_t n_tiles;                        // 16 * patches in the band
@@ -77,14 +79,16 @@ __device__ __forceinline__ void stage_scene(const double *__restrict__ scene_blo
 
 // tile id -> pixel origin.  Patch-major: patch = id / 16 walks the band row by row
 // (renderer.rs:69-70), sub = id % 16 walks the 4x4 tiles of the patch.
-__device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, uint32_t &tx0, uint32_t &ty0) {
+__device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, uint32_t &tx0, uint32_t &ty0, uint32_t &ty8) {
     // Workgroups are dispatched in id order; the affine map (a bijection: order_mul is
     // coprime with n_tiles) decides which part of the image is rendered when.
     const uint32_t tile = (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
     const uint32_t patch = tile >> 4, sub = tile & 15u;
     const uint32_t pcol = patch % a.n_width, prow = patch / a.n_width;
     tx0 = pcol * 32u + (sub & (32u / TILE_W - 1u)) * TILE_W;
-    ty0 = (a.patch_row_begin + prow) * 32u + (sub / (32u / TILE_W)) * TILE_H;
+    const uint32_t in_patch = (sub / (32u / TILE_W)) * TILE_H;
+    ty0 = (a.patch_row_begin + prow * a.patch_row_stride) * 32u + in_patch;
+    ty8 = a.u8_compact ? prow * 32u + in_patch : ty0;           // row of the tile in the u8 frame
 }
 
 }  // namespace rmdev

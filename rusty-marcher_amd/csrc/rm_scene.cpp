@@ -93,6 +93,7 @@ void rm_create_renderer(double fov, double height, double width, rm_params *out)
     out->background = v3(0.1, 0.1, 0.1);
     out->patch_row_begin = 0;
     out->patch_row_end = 0;
+    out->patch_row_stride = 1;
     out->flags = RM_FLAG_NONE;
 }
 

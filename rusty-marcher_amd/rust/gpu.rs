@@ -89,7 +89,7 @@ pub struct RmParams {
     pub patch_row_begin: u32,
     pub patch_row_end: u32,
     pub flags: u32,
-    pub _pad: u32,
+    pub patch_row_stride: u32,
 }
 
 #[repr(C)]

@@ -129,3 +129,46 @@ def test_equal_bands_properties():
             assert all(0 <= e - b <= c for b, e in bands)
             assert all(b == min(r * c, P) for r, (b, e) in enumerate(bands))
     assert workloads.equal_bands(33, 8)[1] == [(0, 5), (5, 10), (10, 15), (15, 20), (20, 25), (25, 30), (30, 33), (33, 33)]
+
+
+def _worker_cyclic(rank, world, port, w, h, depth, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    import workloads
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        O = G.load_oracle()
+        n_rows = h // 32
+        c, owned = workloads.cyclic_rows(n_rows, world)
+        frame = np.zeros((h, w, 3))
+        scene = O.OracleScene.create_default()
+        for row in owned[rank]:
+            O.render(scene, w, h, max_depth=depth, n_threads=1, frame=frame, band=(row, row + 1))
+        # pack this rank's display rows into its chunk of the gather buffer
+        gathered = torch.full((world * c * 32, w, 3), 55, dtype=torch.uint8)
+        u8 = torch.from_numpy(O.to_vec(frame.copy()).reshape(h, w, 3))
+        for k, row in enumerate(owned[rank]):
+            gathered[(rank * c + k) * 32:(rank * c + k + 1) * 32] = u8[row * 32:(row + 1) * 32]
+        work = dist.all_gather_into_tensor(gathered, gathered[rank * c * 32:(rank + 1) * c * 32], async_op=True)
+        work.wait()
+        display = workloads.deinterleave_rows(gathered, world, torch.zeros_like(gathered))
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, display.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 96, 160), (3, 64, 128), (4, 64, 100)])
+def test_cyclic_rows_allgather_and_deinterleave(O, tmp_path, world, w, h):
+    """bench.py's default N > 1 path: cyclic row ownership, packed display bytes, one
+    in-place (async) all-gather, de-interleave at the consumer."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "display.npy")
+    mp.spawn(_worker_cyclic, args=(world, _free_port(), w, h, 3, out), nprocs=world, join=True)
+    got = np.load(out)
+    n_rows = h // 32
+    ref = O.render(O.OracleScene.create_default(), w, h, max_depth=3)
+    assert np.array_equal(got[:n_rows * 32].reshape(-1), O.to_vec(ref[:n_rows * 32].copy()))

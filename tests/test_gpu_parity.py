@@ -576,6 +576,54 @@ def test_bands_tile_the_frame_bitwise(pkg, ctx):
     assert [workloads.patch_rows_for_rank(135, r, 8) for r in range(8)][-1] == (118, 135)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_cyclic_rows_and_packed_display_bytes(pkg, ctx, world):
+    """bench.py's N > 1 path without the network: every rank renders patch rows r, r+N, ...
+    (rm_params stride) into its own full-size f64 frame and packs the display bytes of its
+    rows (RM_FLAG_U8_COMPACT) into its chunk of the gather buffer; the union of the f64 rows
+    and the de-interleaved chunks must equal the single-GPU frame bit for bit."""
+    import torch
+    c = workloads.CONFIGS["C2"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    n_rows = h // 32
+    ctx.upload(pkg.Scene.create_default().flatten())
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    full8 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    p = pkg.backend.make_params(1.5, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    ctx.render_device_u8(p, full.data_ptr(), full8.data_ptr())
+    torch.cuda.synchronize()
+
+    chunk_rows, owned = workloads.cyclic_rows(n_rows, world)
+    assert sorted(r for rows in owned for r in rows) == list(range(n_rows))
+    assert max(len(r) for r in owned) - min(len(r) for r in owned) <= 1
+    parts = torch.zeros_like(full)
+    gathered = torch.full((world * chunk_rows * 32, w, 3), 9, dtype=torch.uint8, device="cuda:0")
+    for r in range(world):
+        pr = pkg.backend.make_params(1.5, float(h), float(w), depth, band=(r, n_rows, world))
+        pr.flags = _FLAGS["value"] | 4                                   # RM_FLAG_U8_COMPACT
+        chunk = gathered[r * chunk_rows * 32:(r + 1) * chunk_rows * 32]
+        ctx.render_device_u8(pr, parts.data_ptr(), chunk.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(parts, full)
+    display = workloads.deinterleave_rows(gathered, world, torch.zeros_like(gathered))
+    assert torch.equal(display[:n_rows * 32], full8[:n_rows * 32])
+
+    # the host-copy entry point honours the stride too: only owned rows are written
+    out = np.full((h, w, 3), -2.)
+    pr = pkg.backend.make_params(1.5, float(h), float(w), depth, band=(1, n_rows, world))
+    pr.flags = _FLAGS["value"]
+    ctx.render(pr, out)
+    ref = full.cpu().numpy()
+    for row in range(n_rows):
+        blk = out[row * 32:(row + 1) * 32]
+        if row % world == 1:
+            assert np.array_equal(blk, ref[row * 32:(row + 1) * 32])
+        else:
+            assert np.all(blk == -2.)
+    assert np.all(out[n_rows * 32:] == -2.)
+
+
 def test_render_is_deterministic(pkg, ctx):
     c = workloads.CONFIGS["C2"]
     scene = pkg.Scene.create_default()

@@ -178,3 +178,22 @@ def allgather_bands(dist, padded, rank, world):
     (ncclAllGather on GPUs) completes it on every rank -- rank 0 is the consumer."""
     rows = padded.shape[0] // world
     dist.all_gather_into_tensor(padded, padded[rank * rows:(rank + 1) * rows])
+
+
+def cyclic_rows(n_patch_rows, world):
+    """Cyclic ownership for load balance (sky rows are cheap, ground rows
+    expensive): rank r owns patch rows r, r + N, r + 2N, ... -- rm_params band
+    (begin = r, end = P, stride = N).  Returns (c, [rows of each rank]) with
+    c = ceil(P / N) the chunk size in patch rows every rank's packed buffer is padded to."""
+    c = -(-n_patch_rows // world) if n_patch_rows else 0
+    return c, [list(range(r, n_patch_rows, world)) for r in range(world)]
+
+
+def deinterleave_rows(gathered, world, out):
+    """`gathered` is the all-gathered [world * c * 32, W, 3] buffer of packed chunks (rank
+    major: chunk r holds rank r's rows r, r+N, ... in order); writes the frame in image
+    order into `out` (same shape; rows past the last real patch row are padding)."""
+    rows, w, ch = gathered.shape
+    c = rows // (world * 32)
+    out.view(c, world, 32, w, ch).copy_(gathered.view(world, c, 32, w, ch).permute(1, 0, 2, 3, 4))
+    return out
