@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev helper: one bench.py run per line of env assignments read from stdin, e.g.
-#   printf 'RM_KERNEL_MODE=s1x1\nRM_KERNEL_MODE=s4x4 RM_FORCE_GENERIC_POW=1\n' | bash profiles/ab_env.sh [bench args]
+#   printf 'RM_TILE_ORDER=natural\nRM_FORCE_FAST_FP=1 RM_FORCE_GENERIC_POW=1\n' | bash profiles/ab_env.sh [bench args]
 # (separate processes: use it to rank variants coarsely; close calls need the
 # in-process interleaved A/B of profiles/ab_inprocess.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}

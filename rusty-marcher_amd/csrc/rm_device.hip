@@ -79,14 +79,15 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // Context
 // ---------------------------------------------------------------------------
 
-// How the 8x8 tiles of a band are handed to waves (see rm_render_kernel.hpp): `waves`
+// How the 64-pixel tiles of a band are handed to waves (see rm_render_kernel.hpp): `waves`
 // waves per workgroup, `per_wave` tiles per wave.  Measured at 1080p on the demo scene
 // (profiles/r01_ab_launch_modes.txt): one tile per wave wins (finer units for the
 // hardware dispatcher: 4 tiles per wave 193 us vs 1 tile 122 us); 1 or 4 waves per
 // workgroup differ by ~2 %, so larger scenes share one LDS copy between 4 waves.
 // A persistent variant (waves pulling tiles from a global counter) was measured too and
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
-// RM_KERNEL_MODE="s<waves>x<tiles>" overrides the choice for A/B measurements.
+// This build instantiates one tile per wave only (1 wave per workgroup with the LDS scene
+// copy, 4 without); the other geometries were measured with earlier builds.
 struct rm_launch_mode {
     int waves = 0;      // waves per workgroup; 0 = choose from the scene size at launch
     int per_wave = 1;   // tiles per wave

@@ -3,9 +3,9 @@
 // Replaces Renderer::render's Rayon patch loop (renderer.rs:63-89), the serial
 // scatter (renderer.rs:92-108) and cast_ray's recursion (renderer.rs:254-309).
 //
-// Unit of work: an 8x8 pixel TILE rendered by one 64-lane wave, one lane per
+// Unit of work: a 64-pixel TILE (16x4) rendered by one 64-lane wave, one lane per
 // pixel (the 64 rays of a wave stay spatially coherent: same primitives hit,
-// same branches; measured VALU lane utilisation 94 %).  Sixteen tiles make one of
+// same branches; measured VALU lane utilisation 87-94 %).  Sixteen tiles make one of
 // the reference's 32x32 patches (renderer.rs:47); tile ids are patch-major so a
 // run of 16 consecutive ids is exactly one reference patch.
 //
