@@ -569,7 +569,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     unsigned long long *d_stamps = nullptr;
     const size_t n_waves = (size_t)grid.x * m.waves;
     RM_HIP(ctx, hipMalloc(&d_stamps, n_waves * 32));
-    RM_HIP(ctx, hipMemset(d_stamps, 0, n_waves * 32));
+    RM_HIP(ctx, hipMemsetAsync(d_stamps, 0, n_waves * 32, stream));
     a.debug_stamps = d_stamps;
 #endif
     void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
