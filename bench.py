@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the per-frame collective even at world size 1 (smoke test of the N > 1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the short 4K / 8K runs reported beside the metric")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
     args = ap.parse_args()
 
@@ -122,118 +123,146 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = G.load_package()
-    cfg = workloads.CONFIGS[args.config]
-    w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
-    n_rows = h // 32
-    # N > 1, u8 payload: cyclic row ownership (rank r renders patch rows r, r+N, ...: every
-    # rank gets its share of cheap sky and expensive ground rows) with the display bytes
-    # packed per rank; f64 payload: contiguous equal bands gathered in place.
-    cyclic = world > 1 and args.payload == "u8"
-    if cyclic:
-        c_rows, owned = workloads.cyclic_rows(n_rows, world)
-        band = (rank, n_rows, world)
-        n_owned = len(owned[rank])
-    else:
-        c_rows, bands = workloads.equal_bands(n_rows, world)
-        band = bands[rank]
-        n_owned = band[1] - band[0]
-
-    ctx = pkg.backend.Context(local_rank)
-    scene = workloads.product_scene(pkg, cfg["scene"])
-    ctx.upload(scene.flatten())
-    params = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
-    if args.fast_fp:
-        params.flags |= 2                                              # RM_FLAG_FAST_FP
-    if cyclic:
-        params.flags |= 4                                              # RM_FLAG_U8_COMPACT
-    # Per rank: the f64 frame (create_frame_buffer zero-fills; this rank's band of it is
-    # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
-    # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
-    pad_h = max(h, world * c_rows * 32)
-    # Two frames in flight at N > 1: frame k's collective runs on RCCL's stream while frame
-    # k+1 renders (double-buffered), so steady-state throughput is 1 / max(render, gather).
-    n_buf = 2 if use_dist else 1
-    frames = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
-    frames8 = [torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-    frame, frame8 = frames[0], frames8[0]
-    gathered = [(f8 if args.payload == "u8" else f)[:world * c_rows * 32] for f, f8 in zip(frames, frames8)]
-    my_chunk = [g[rank * c_rows * 32:(rank + 1) * c_rows * 32] for g in gathered]   # views built once
-    # A dedicated stream: the kernel, the timing events and the RCCL op are all ordered
-    # on it (torch.cuda.Event only sees the stream it is recorded on).
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(stream)
     L = pkg.lib()
-    p_ref = C.byref(params)
-    frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
-    # cyclic: the kernel packs this rank's display rows straight into its chunk of the gather buffer
-    frame8_ptrs = [C.c_void_p((ch if cyclic else f8).data_ptr()) for ch, f8 in zip(my_chunk, frames8)]
-    display = torch.zeros_like(gathered[0]) if cyclic and rank == 0 else None   # image-order frame at the consumer
-    stream_ptr = C.c_void_p(stream.cuda_stream)
-    has_rows = n_owned > 0
-    pending = [None] * n_buf
-    counter = [0]
 
-    def step():
-        """One frame: render this rank's band (f64 rows + their display bytes), then the
-        single collective of the frame (asynchronous: the stream is only made to wait for
-        it when its buffer is about to be rendered into again)."""
-        b = counter[0] % n_buf
-        counter[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()                      # stream-ordered; the host does not block
-            pending[b] = None
-            if display is not None:
-                workloads.deinterleave_rows(gathered[b], world, display)
-        if has_rows:
-            st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], frame8_ptrs[b], stream_ptr)
-            if st != 0:
-                raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
-        if use_dist:
-            pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
+    def run_workload(cfg_id, steps, warmup):
+        """Warm-up, then `steps` frames of one workload between fences; returns the
+        timings and what rank 0 holds afterwards."""
+        cfg = workloads.CONFIGS[cfg_id]
+        w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
+        n_rows = h // 32
+        # N > 1, u8 payload: cyclic row ownership (rank r renders patch rows r, r+N, ...: every
+        # rank gets its share of cheap sky and expensive ground rows) with the display bytes
+        # packed per rank; f64 payload: contiguous equal bands gathered in place.
+        cyclic = world > 1 and args.payload == "u8"
+        if cyclic:
+            c_rows, owned = workloads.cyclic_rows(n_rows, world)
+            band = (rank, n_rows, world)
+            n_owned = len(owned[rank])
+        else:
+            c_rows, bands = workloads.equal_bands(n_rows, world)
+            band = bands[rank]
+            n_owned = band[1] - band[0]
 
-    def drain():
-        for i, wk in enumerate(pending):
-            if wk is not None:
-                wk.wait()
-                pending[i] = None
+        ctx = pkg.backend.Context(local_rank)
+        scene = workloads.product_scene(pkg, cfg["scene"])
+        ctx.upload(scene.flatten())
+        params = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
+        if args.fast_fp:
+            params.flags |= 2                                              # RM_FLAG_FAST_FP
+        if cyclic:
+            params.flags |= 4                                              # RM_FLAG_U8_COMPACT
+        # Per rank: the f64 frame (create_frame_buffer zero-fills; this rank's band of it is
+        # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
+        # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
+        pad_h = max(h, world * c_rows * 32)
+        # Two frames in flight at N > 1: frame k's collective runs on RCCL's stream while frame
+        # k+1 renders (double-buffered), so steady-state throughput is 1 / max(render, gather).
+        n_buf = 2 if use_dist else 1
+        frames = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
+        frames8 = [torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+        frame, frame8 = frames[0], frames8[0]
+        gathered = [(f8 if args.payload == "u8" else f)[:world * c_rows * 32] for f, f8 in zip(frames, frames8)]
+        my_chunk = [g[rank * c_rows * 32:(rank + 1) * c_rows * 32] for g in gathered]   # views built once
+        # A dedicated stream: the kernel, the timing events and the RCCL op are all ordered
+        # on it (torch.cuda.Event only sees the stream it is recorded on).
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(stream)
+        p_ref = C.byref(params)
+        frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
+        # cyclic: the kernel packs this rank's display rows straight into its chunk of the gather buffer
+        frame8_ptrs = [C.c_void_p((ch if cyclic else f8).data_ptr()) for ch, f8 in zip(my_chunk, frames8)]
+        display = torch.zeros_like(gathered[0]) if cyclic and rank == 0 else None   # image-order frame at the consumer
+        stream_ptr = C.c_void_p(stream.cuda_stream)
+        has_rows = n_owned > 0
+        pending = [None] * n_buf
+        counter = [0]
+
+        def step():
+            """One frame: render this rank's band (f64 rows + their display bytes), then the
+            single collective of the frame (asynchronous: the stream is only made to wait for
+            it when its buffer is about to be rendered into again)."""
+            b = counter[0] % n_buf
+            counter[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()                      # stream-ordered; the host does not block
+                pending[b] = None
                 if display is not None:
-                    workloads.deinterleave_rows(gathered[i], world, display)
+                    workloads.deinterleave_rows(gathered[b], world, display)
+            if has_rows:
+                st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], frame8_ptrs[b], stream_ptr)
+                if st != 0:
+                    raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
+            if use_dist:
+                pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
 
-    def fence():
-        drain()
-        torch.cuda.synchronize()
+        def drain():
+            for i, wk in enumerate(pending):
+                if wk is not None:
+                    wk.wait()
+                    pending[i] = None
+                    if display is not None:
+                        workloads.deinterleave_rows(gathered[i], world, display)
+
+        def fence():
+            drain()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            step()
+        # HIP events on the launch stream bracket the timed region (one pair: an event per
+        # launch would put two extra packets between consecutive kernels)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for k in range(steps):
+            step()
+        ev1.record(stream)
+        fence()
+        elapsed = time.perf_counter() - t0
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
 
-    for _ in range(args.warmup):
-        step()
-    # HIP events on the launch stream bracket the timed region (one pair: an event per
-    # launch would put two extra packets between consecutive kernels)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fence()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(args.steps):
-        step()
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
+        # average launch duration of this rank's render kernel over the timed region (for
+        # N > 1 the gather's stream time is inside the bracket too, so it is only reported
+        # as the kernel's duration at N = 1)
+        kernel_ms = ev0.elapsed_time(ev1) / steps
+        px_launch = n_owned * 32 * w                                        # pixels one launch writes
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic,
+                   elapsed=elapsed, kernel_ms=kernel_ms, px_launch=px_launch,
+                   mpx=(w * h) * steps / elapsed / 1e6,
+                   frame=frame, frame8=frame8, display=display)
+        ctx.close()
+        return res
 
-    # average launch duration of this rank's render kernel over the timed region (for
-    # N > 1 the gather's stream time is inside the bracket too, so it is only reported
-    # as the kernel's duration at N = 1)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    px_launch = n_owned * 32 * w                                        # pixels one launch writes
+    r = run_workload(args.config, args.steps, args.warmup)
+    cfg, w, h, depth, n_rows, c_rows, cyclic = (r[k] for k in ("cfg", "w", "h", "depth", "n_rows", "c_rows", "cyclic"))
+    elapsed, kernel_ms, px_launch = r["elapsed"], r["kernel_ms"], r["px_launch"]
+    frame, frame8, display = r["frame"], r["frame8"], r["display"]
+    # north star: "Mpixels/sec on synthetic 1080p/4K/8K frames": the larger frames of the
+    # same scene, a short run each (same sharding and collective), reported beside the metric
+    other = []
+    if args.config == "C2" and not args.no_sizes:
+        for cid in ("C2_4K", "C4"):
+            o = run_workload(cid, max(5, min(args.steps, 20)), 3)
+            ach = o["px_launch"] * BYTES_PER_PIXEL / (o["kernel_ms"] * 1e-3) / 1e9
+            other.append({"workload": "%s: %s scene %dx%d, depth cap %d" % (cid, o["cfg"]["scene"], o["w"], o["h"], o["depth"]),
+                          "value": o["mpx"], "unit": "Mpixels/s", "ms_per_step": o["elapsed"] / max(5, min(args.steps, 20)) * 1e3,
+                          "roofline_frac": (ach / HBM_PEAK_GBPS) if world == 1 else None})
+            o.clear()
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        mpx = (w * h) * args.steps / elapsed / 1e6
+        mpx = r["mpx"]
         achieved = px_launch * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
         traffic, valu = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -285,13 +314,14 @@ def main():
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, cfg)
             out["speedup_vs_cpu_baseline"] = mpx / out["cpu_baseline"]["value"]
+        if other:
+            out["other_frames"] = other
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

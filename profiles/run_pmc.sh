@@ -16,7 +16,7 @@ for grp in \
   "FETCH_SIZE" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sizes "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -26,6 +26,7 @@ CONFIGS = {
     "C2": dict(scene="demo", width=1920, height=1080, max_depth=5),
     "C3": dict(scene="cornell", width=1920, height=1080, max_depth=5),
     "C4": dict(scene="demo", width=7680, height=4320, max_depth=8),
+    "C2_4K": dict(scene="demo", width=3840, height=2160, max_depth=5),     # north star's 4K point (C2 at 4K)
     "C5": dict(scene="synthetic256", width=4096, height=4096, max_depth=10),
     # the reference's own operating points (depth cap 3, renderer.rs:262)
     "REF800": dict(scene="demo", width=800, height=600, max_depth=3),      # engine/out.ppm
