@@ -1,8 +1,8 @@
 #!/bin/bash
 # Dev helper: one bench.py run per line of env assignments read from stdin, e.g.
 #   printf 'RM_TILE_ORDER=natural\nRM_FORCE_FAST_FP=1 RM_FORCE_GENERIC_POW=1\n' | bash profiles/ab_env.sh [bench args]
-# (separate processes: use it to rank variants coarsely; close calls need the
-# in-process interleaved A/B of profiles/ab_inprocess.py)
+# (separate processes, box-to-box and run-to-run noise is ~2 %: repeat the lines to
+# interleave variants when the difference is small)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 while read -r line; do
   [ -z "$line" ] && continue

@@ -55,6 +55,11 @@ struct KernelArgs {
     unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
 };
 
+// Copies a wave-uniform value into a scalar register of its own (see the kernel's header copy).
+// (a real move: an empty asm with a tied operand is coalesced back into the tuple)
+__device__ __forceinline__ double own_sgpr(double v) { double r; asm("s_mov_b64 %0, %1" : "=s"(r) : "s"(v)); return r; }
+__device__ __forceinline__ uint32_t own_sgpr(uint32_t v) { uint32_t r; asm("s_mov_b32 %0, %1" : "=s"(r) : "s"(v)); return r; }
+
 struct StackEntry {
     double ox, oy, oz, dx, dy, dz, w;
     uint32_t depth, _pad;
