@@ -237,7 +237,25 @@ def main():
         kernel_ms = ev0.elapsed_time(ev1) / steps
         px_launch = n_owned * 32 * w                                        # pixels one launch writes
 
-        res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic,
+        # the drop-in call itself, rm_render into pageable host memory
+        # (what Renderer::render hands back), a few frames outside the timed region
+        host = None
+        if world == 1 and rank == 0 and cfg_id == args.config:
+            torch.cuda.synchronize()
+            host_frame = np.zeros((h, w, 3), dtype=np.float64)
+            p_host = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
+            p_host.flags = params.flags & 2
+            ctx.render(p_host, host_frame)
+            ts, tm = [], None
+            for _ in range(10):
+                t1 = time.perf_counter()
+                tm = ctx.render(p_host, host_frame)
+                ts.append(time.perf_counter() - t1)
+            med = float(np.median(ts))
+            host = {"value": w * h / med / 1e6, "unit": "Mpixels/s", "ms_per_frame": med * 1e3,
+                    "kernel_ms": tm.kernel_ms, "d2h_ms": tm.d2h_ms,
+                    "what": "rm_render(): kernel + device-to-host copy of the f64 frame into pageable memory, median of 10"}
+        res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic, host=host,
                    elapsed=elapsed, kernel_ms=kernel_ms, px_launch=px_launch,
                    mpx=(w * h) * steps / elapsed / 1e6,
                    frame=frame, frame8=frame8, display=display)
@@ -314,6 +332,8 @@ def main():
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, cfg)
             out["speedup_vs_cpu_baseline"] = mpx / out["cpu_baseline"]["value"]
+        if r["host"]:
+            out["end_to_end_host"] = r["host"]
         if other:
             out["other_frames"] = other
         json_out.write(json.dumps(out) + "\n")
