@@ -87,7 +87,11 @@ __device__ __forceinline__ void stage_scene(const double *__restrict__ scene_blo
 __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, uint32_t &tx0, uint32_t &ty0, uint32_t &ty8) {
     // Workgroups are dispatched in id order; the affine map (a bijection: order_mul is
     // coprime with n_tiles) decides which part of the image is rendered when.
-    const uint32_t tile = (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
+    // (natural and bottom-up order, the two that ship, without the 64-bit modulo)
+    const uint32_t last = a.n_tiles - 1u;
+    const uint32_t tile = (a.order_mul == 1u && a.order_add == 0u) ? id
+                        : (a.order_mul == last && a.order_add == last) ? last - id
+                        : (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
     const uint32_t patch = tile >> 4, sub = tile & 15u;
     const uint32_t pcol = patch % a.n_width, prow = patch / a.n_width;
     tx0 = pcol * 32u + (sub & (32u / TILE_W - 1u)) * TILE_W;
