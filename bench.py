@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the per-frame collective even at world size 1 (smoke test of the N > 1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sizes", action="store_true", help="skip the short 4K / 8K runs reported beside the metric")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the extras reported beside the metric (4K / 8K frames, rm_render into host memory)")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
     args = ap.parse_args()
 
@@ -240,7 +240,7 @@ def main():
         # the drop-in call itself, rm_render into pageable host memory
         # (what Renderer::render hands back), a few frames outside the timed region
         host = None
-        if world == 1 and rank == 0 and cfg_id == args.config:
+        if world == 1 and rank == 0 and cfg_id == args.config and not args.no_sizes:
             torch.cuda.synchronize()
             host_frame = np.zeros((h, w, 3), dtype=np.float64)
             p_host = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
