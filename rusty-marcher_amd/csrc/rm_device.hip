@@ -420,6 +420,8 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
             const rm_vec3 &q = d->polygon_vertices[p.first_vertex + v];
             blob[H.off_pverts + RM_PVERT_WORDS * pv] = q.x;
             blob[H.off_pverts + RM_PVERT_WORDS * pv + 1] = q.y;
+            // the first four also travel in the record: one fetch per polygon, not two dependent ones
+            if (v < 4) { w[8 + 2 * v] = q.x; w[9 + 2 * v] = q.y; }
         }
         put_material(pid, p.reflectance);
     }

@@ -42,7 +42,7 @@ struct rm_dev_header {
 };
 
 #define RM_SPHERE_WORDS 4u
-#define RM_POLYGON_WORDS 8u
+#define RM_POLYGON_WORDS 16u   /* normal, plane point, (first vertex | count), pad, x/y of the first four vertices */
 #define RM_PVERT_WORDS 2u
 #define RM_TRIANGLE_WORDS 12u
 #define RM_MATERIAL_WORDS 10u
