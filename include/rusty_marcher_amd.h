@@ -43,7 +43,8 @@ typedef enum rm_status {
     RM_ERR_IO = 7,           /* file missing (obj.rs:53-56 returns None; a missing mtllib
                                 panics "WOOPS", obj.rs:64) */
     RM_ERR_PARSE = 8,
-    RM_ERR_DEPTH = 9         /* max_depth outside [0, RM_MAX_DEPTH] */
+    RM_ERR_DEPTH = 9,        /* max_depth outside [0, RM_MAX_DEPTH] */
+    RM_ERR_COMM = 10         /* RCCL unavailable or a collective failed (rm_comm_*, rm_frame_*) */
 } rm_status;
 
 /* Recursion cap accepted by rm_render.  The reference hard-codes 3
@@ -257,6 +258,46 @@ rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes);
  */
 rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t frame_width, uint32_t frame_height,
                          int normalize, uint8_t *host_rgb8, double *max_out);
+
+/* ---- multi-GPU frames: one process per GPU, RCCL over xGMI ----------------------------
+ * Replaces, for N GPUs, what renderer.rs:63-108 does with N Rayon workers: the patch rows
+ * of a frame are owned cyclically (rank r renders patch rows r, r+N, r+2N, ... so that
+ * every rank gets its share of cheap sky and expensive ground rows), each rank's f64 rows
+ * stay in its own `device_rgb` (a distributed FrameBuffer), and ONE in-place RCCL
+ * all-gather per frame completes the display frame (`to_vec` bytes, framebuffer.rs:40-55)
+ * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot renders on a
+ * stream of its own and the collectives run on one exchange stream in submission order,
+ * so every rank must submit the same sequence of frames.
+ *
+ * Bootstrap: rank 0 calls rm_comm_unique_id and hands the RM_COMM_ID_BYTES to the other
+ * ranks by any channel (a file, a socket, torch.distributed's store); every rank then
+ * calls rm_comm_init.  id == NULL sets rank/world without a transport: the layout is that
+ * of `world` ranks but nothing is exchanged (single-GPU tests of the N-GPU layout).
+ */
+#define RM_COMM_ID_BYTES 128u
+#define RM_MAX_FRAME_SLOTS 4u
+rm_status rm_comm_unique_id(void *id_out /* RM_COMM_ID_BYTES */);
+rm_status rm_comm_init(rm_ctx *ctx, const void *id, int rank, int world);
+void rm_comm_destroy(rm_ctx *ctx);   /* also done by rm_destroy */
+
+/* Layout of the gather buffer for `world` ranks: world chunks of rows_per_rank patch rows
+ * (32 * frame_width * 3 bytes each); chunk k holds patch rows k, k+world, ... packed. */
+rm_status rm_exchange_layout(const rm_params *params, int world, uint32_t *rows_per_rank, size_t *chunk_bytes);
+
+/*
+ * One frame, asynchronously: renders this rank's rows into device_rgb ([H][W][3] f64,
+ * only the owned rows are written) and their display bytes into this rank's chunk of
+ * device_gather8 (world * chunk_bytes), all-gathers the chunks in place, and -- where
+ * device_display8 is not NULL (the consumer, e.g. rank 0's window) -- writes the
+ * [32*n_patch_rows][W][3] image-order display frame.  params->patch_row_* must be zero.
+ * The buffers belong to `slot` until rm_frame_wait(slot) returns or the slot is submitted
+ * again (which orders itself after the slot's previous exchange).
+ */
+rm_status rm_frame_submit(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_gather8,
+                          void *device_display8, uint32_t slot);
+/* Blocks the host until the slot's last frame is complete on this rank. */
+rm_status rm_frame_wait(rm_ctx *ctx, uint32_t slot);
+
 
 /* Library / device introspection for harnesses. */
 uint32_t    rm_abi_version(void);

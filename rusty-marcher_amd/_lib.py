@@ -9,13 +9,15 @@ LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(_HERE, "lib", "librusty
 RM_OK = 0
 RM_ERR_INVALID_ARG, RM_ERR_DIMENSIONS, RM_ERR_NO_DEVICE, RM_ERR_HIP = 1, 2, 3, 4
 RM_ERR_NO_SCENE, RM_ERR_SCENE_LIMIT, RM_ERR_IO, RM_ERR_PARSE, RM_ERR_DEPTH = 5, 6, 7, 8, 9
+RM_ERR_COMM = 10
 RM_MAX_DEPTH = 32
+RM_COMM_ID_BYTES, RM_MAX_FRAME_SLOTS = 128, 4
 RM_PATCH_SIZE = 32
 RM_SHAPE_SPHERE, RM_SHAPE_POLYGON, RM_SHAPE_MESH = 0, 1, 2
 
 STATUS_NAMES = {0: "RM_OK", 1: "RM_ERR_INVALID_ARG", 2: "RM_ERR_DIMENSIONS", 3: "RM_ERR_NO_DEVICE",
                 4: "RM_ERR_HIP", 5: "RM_ERR_NO_SCENE", 6: "RM_ERR_SCENE_LIMIT", 7: "RM_ERR_IO",
-                8: "RM_ERR_PARSE", 9: "RM_ERR_DEPTH"}
+                8: "RM_ERR_PARSE", 9: "RM_ERR_DEPTH", 10: "RM_ERR_COMM"}
 
 
 class rm_vec3(C.Structure):
@@ -105,6 +107,12 @@ SIGNATURES = {
     "rm_render_device_u8": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP]),
     "rm_device_framebuffer": (C.c_int, [_VP, _P(_VP), _P(C.c_size_t)]),
     "rm_postprocess": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_int, _P(C.c_uint8), _P(C.c_double)]),
+    "rm_comm_unique_id": (C.c_int, [_VP]),
+    "rm_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "rm_comm_destroy": (None, [_VP]),
+    "rm_exchange_layout": (C.c_int, [_P(rm_params), C.c_int, _P(C.c_uint32), _P(C.c_size_t)]),
+    "rm_frame_submit": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP, C.c_uint32]),
+    "rm_frame_wait": (C.c_int, [_VP, C.c_uint32]),
     "rm_abi_version": (C.c_uint32, []),
     "rm_build_info": (C.c_char_p, []),
     "rm_device_info": (C.c_int, [_VP, C.c_char_p, C.c_size_t, _P(C.c_int), _P(C.c_size_t)]),

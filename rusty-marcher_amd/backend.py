@@ -48,6 +48,35 @@ class Context:
                                               C.c_void_p(device_ptr8), C.c_void_p(stream) if stream else None),
                    self.ptr)
 
+    # ---- multi-GPU frames (include/rusty_marcher_amd.h, rm_comm_* / rm_frame_*) ----
+    @staticmethod
+    def comm_unique_id():
+        """RM_COMM_ID_BYTES from RCCL: rank 0 makes one and hands it to the other ranks."""
+        buf = C.create_string_buffer(_lib.RM_COMM_ID_BYTES)
+        _lib.check(_lib.lib().rm_comm_unique_id(buf), None)
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id=None):
+        """unique_id None: the layout of `world` ranks without a transport (tests)."""
+        if unique_id is not None and len(unique_id) != _lib.RM_COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.RM_COMM_ID_BYTES)
+        _lib.check(self.L.rm_comm_init(self.ptr, unique_id, rank, world), self.ptr)
+
+    def comm_destroy(self):
+        self.L.rm_comm_destroy(self.ptr)
+
+    def exchange_layout(self, params, world):
+        rows, chunk = C.c_uint32(0), C.c_size_t(0)
+        _lib.check(self.L.rm_exchange_layout(C.byref(params), world, C.byref(rows), C.byref(chunk)), self.ptr)
+        return rows.value, chunk.value
+
+    def frame_submit(self, params, device_ptr, gather_ptr, display_ptr=None, slot=0):
+        _lib.check(self.L.rm_frame_submit(self.ptr, C.byref(params), C.c_void_p(device_ptr), C.c_void_p(gather_ptr),
+                                          C.c_void_p(display_ptr) if display_ptr else None, slot), self.ptr)
+
+    def frame_wait(self, slot=0):
+        _lib.check(self.L.rm_frame_wait(self.ptr, slot), self.ptr)
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, lds = C.c_int(0), C.c_size_t(0)

@@ -102,6 +102,13 @@ static bool parse_mode(const char *s, rm_launch_mode *m) {
 // dispatch order of the tiles (tile_origin): RM_TILE_ORDER = natural | reverse | hash
 enum { TILE_ORDER_NATURAL = 0, TILE_ORDER_REVERSE = 1, TILE_ORDER_HASH = 2 };
 
+// A frame in flight (rm_frame_submit): its own render stream, so that consecutive frames overlap.
+struct rm_frame_slot {
+    hipStream_t render = nullptr;
+    hipEvent_t rendered = nullptr, exchanged = nullptr;
+    bool used = false;
+};
+
 struct rm_ctx {
     int device = -1;
     rm_launch_mode mode;
@@ -132,6 +139,13 @@ struct rm_ctx {
     double *d_frame = nullptr;
     size_t frame_bytes = 0;
     uint32_t frame_w = 0, frame_h = 0;
+
+    // multi-GPU frames (rm_exchange.inc)
+    void *comm = nullptr;             // ncclComm_t
+    bool comm_local = false;          // rank/world set without a transport (rm_comm_init with id == NULL)
+    int rank = 0, world = 1;
+    hipStream_t xchg_stream = nullptr;
+    rm_frame_slot slots[RM_MAX_FRAME_SLOTS];
 
     // post-process scratch
     unsigned long long *d_max = nullptr;
@@ -260,6 +274,13 @@ void rm_destroy(rm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rm_comm_destroy(ctx);
+    for (rm_frame_slot &s : ctx->slots) {
+        if (s.render) { (void)hipStreamSynchronize(s.render); (void)hipStreamDestroy(s.render); }
+        if (s.rendered) (void)hipEventDestroy(s.rendered);
+        if (s.exchanged) (void)hipEventDestroy(s.exchanged);
+    }
+    if (ctx->xchg_stream) (void)hipStreamDestroy(ctx->xchg_stream);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_max) (void)hipFree(ctx->d_max);
@@ -721,3 +742,5 @@ rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, 
 }
 
 }  // extern "C"
+
+#include "rm_exchange.inc"

@@ -624,6 +624,79 @@ def test_cyclic_rows_and_packed_display_bytes(pkg, ctx, world):
     assert np.all(out[n_rows * 32:] == -2.)
 
 
+@pytest.mark.parametrize("world", [1, 2, 5, 8])
+def test_frame_submit_layout_of_n_ranks_on_one_gpu(pkg, world):
+    """rm_frame_submit (the C ABI's multi-GPU frame) with the layout of `world` ranks and no
+    transport (rm_comm_init with a NULL id): the ranks take turns on this one GPU, each
+    writes its cyclic rows and its chunk of the shared gather buffer, and the consumer's
+    de-interleaved display frame must be the single-GPU frame bit for bit."""
+    import torch
+    c = workloads.CONFIGS["C2"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    n_rows = h // 32
+    cx = pkg.backend.Context(0)
+    cx.upload(pkg.Scene.create_default().flatten())
+    p = pkg.backend.make_params(1.5, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    full8 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    cx.render_device_u8(p, full.data_ptr(), full8.data_ptr())
+    torch.cuda.synchronize()
+
+    rows, chunk = cx.exchange_layout(p, world)
+    assert rows == -(-n_rows // world) and chunk == rows * 32 * w * 3
+    parts = torch.zeros_like(full)
+    gathered = torch.full((world * chunk,), 7, dtype=torch.uint8, device="cuda:0")
+    display = torch.full((n_rows * 32, w, 3), 9, dtype=torch.uint8, device="cuda:0")
+    for r in range(world):
+        cx.comm_init(r, world)
+        last = r == world - 1
+        cx.frame_submit(p, parts.data_ptr(), gathered.data_ptr(), display.data_ptr() if last else None, slot=r % 4)
+        cx.frame_wait(r % 4)
+    assert torch.equal(parts, full)
+    assert torch.equal(display, full8[:n_rows * 32])
+    with pytest.raises(pkg.BackendError):                       # the band is the library's business here
+        cx.frame_submit(pkg.backend.make_params(1.5, float(h), float(w), depth, band=(0, 4)), parts.data_ptr(),
+                        gathered.data_ptr())
+    cx.close()
+
+
+def test_frame_submit_through_rccl_world_of_one(pkg):
+    """The RCCL leg with the one rank this box has: communicator from rm_comm_unique_id /
+    rm_comm_init, several frames in flight over the slots (each on a stream of its own),
+    camera moved between frames; every slot's display and f64 frame must equal the plain
+    single-stream render of the same camera."""
+    import torch
+    c = workloads.CONFIGS["SHOT"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    n_rows = h // 32
+    cx = pkg.backend.Context(0)
+    scene = pkg.Scene.create_default()
+    cx.upload(scene.flatten())
+    cx.comm_init(0, 1, pkg.backend.Context.comm_unique_id())
+    p = pkg.backend.make_params(1.5, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    n_slots = 4
+    f64 = [torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0") for _ in range(n_slots)]
+    g8 = [torch.zeros((n_rows * 32, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(n_slots)]
+    d8 = [torch.zeros((n_rows * 32, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(n_slots)]
+    cams = [(0., 0., 0.), (0., 5., 0.), (-5., 0., 0.), (0., 0., -5.), (5., 5., 0.), (0., 0., 0.), (0., -5., 5.), (5., 0., 0.)]
+    for k, cam in enumerate(cams):                              # two rounds over the slots
+        cx.set_camera(cam)
+        cx.frame_submit(p, f64[k % n_slots].data_ptr(), g8[k % n_slots].data_ptr(), d8[k % n_slots].data_ptr(), slot=k % n_slots)
+    for s in range(n_slots):
+        cx.frame_wait(s)
+    ref = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    ref8 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    for s in range(n_slots):
+        cx.set_camera(cams[n_slots + s])
+        cx.render_device_u8(p, ref.data_ptr(), ref8.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(f64[s], ref), "slot %d f64" % s
+        assert torch.equal(d8[s], ref8[:n_rows * 32]) and torch.equal(g8[s], ref8[:n_rows * 32]), "slot %d u8" % s
+    cx.close()
+
+
 def test_render_is_deterministic(pkg, ctx):
     c = workloads.CONFIGS["C2"]
     scene = pkg.Scene.create_default()
