@@ -9,10 +9,14 @@ A step is one frame of the workload: BASELINE.json's configs[1] (demo scene,
 1920x1080, depth cap 5) unless --config says otherwise.  Each launch writes the f64 RGB
 frame (the reference's FrameBuffer) and its display bytes (`to_vec`, what the UI blits)
 to HBM; inputs (the scene) are uploaded before the timed region.
-N > 1: the frame is sharded by equal bands of 32-row patch rows, every
-rank renders its band, and ONE in-place RCCL all-gather per frame, inside the timed
-region, completes the display frame on every rank (--payload u8, default; rank 0 is
-the consumer) or the f64 frame (--payload f64).  Total work is fixed: "strong" scaling.
+N > 1: the frame is sharded by 32-row patch rows (cyclic ownership: rank r
+renders patch rows r, r+N, ...), and ONE in-place RCCL all-gather per frame, inside the
+timed region, completes the display frame on every rank (--payload u8, default; rank 0 is
+the consumer) or the f64 frame (--payload f64, contiguous bands).  The default exchange is
+the library's own (rm_frame_submit: three frames in flight, each rendering on a stream of
+its own, ncclAllGather issued from C); its first frame is checked byte for byte against
+torch.distributed.all_gather_into_tensor, which takes over if they disagree
+(--collective torch selects it outright).  Total work is fixed: "strong" scaling.
 
 Rank 0 prints ONE JSON line.  Metric definition follows the reference
 (renderer.rs:113-120): frame_width x frame_height pixels per frame / wall time.
@@ -77,6 +81,11 @@ def main():
     ap.add_argument("--payload", choices=["u8", "f64"], default="u8",
                     help="what the per-frame all-gather moves at N > 1: the display bytes (to_vec, 3 B/px) "
                          "or the f64 rows (24 B/px)")
+    ap.add_argument("--collective", choices=["direct", "torch"], default="direct",
+                    help="N > 1, u8 payload: 'direct' = the library's own frame exchange (rm_frame_submit: frames in "
+                         "flight on their own streams, ncclAllGather called from C; checked against the torch path "
+                         "on the first frame, falls back to it on any disagreement); 'torch' = "
+                         "torch.distributed.all_gather_into_tensor per frame")
     ap.add_argument("--fast-fp", action="store_true",
                     help="RM_FLAG_FAST_FP flavour of the kernel (FMA, Newton rsqrt): faster, but may decide "
                          "exact-incidence pixels differently from the reference -- not the parity configuration")
@@ -125,6 +134,37 @@ def main():
     pkg = G.load_package()
     L = pkg.lib()
 
+    # How the frames are exchanged at N > 1 (decided once, the same on every rank).
+    mode = {"collective": "none", "note": None}
+    if use_dist:
+        mode["collective"] = "torch"
+        if args.collective == "direct" and args.payload == "u8" and backend == "nccl":
+            mode["collective"] = "direct"
+
+    def make_comm(ctx):
+        """RCCL communicator of the library's own frame exchange; the unique id travels
+        through torch.distributed.  Every rank learns whether every rank succeeded."""
+        ids = [None]
+        if rank == 0:
+            try:
+                ids[0] = pkg.backend.Context.comm_unique_id()
+            except Exception as e:                     # noqa: BLE001 -- reported, then the torch path is used
+                sys.stderr.write("rm_comm_unique_id failed: %s\n" % e)
+        dist.broadcast_object_list(ids, src=0)
+        ok = 0
+        if ids[0] is not None:
+            try:
+                ctx.comm_init(rank, world, ids[0])
+                ok = 1
+            except Exception as e:                     # noqa: BLE001
+                sys.stderr.write("rank %d: rm_comm_init failed: %s\n" % (rank, e))
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            ctx.comm_destroy()
+            return False
+        return True
+
     def run_workload(cfg_id, steps, warmup):
         """Warm-up, then `steps` frames of one workload between fences; returns the
         timings and what rank 0 holds afterwards."""
@@ -134,7 +174,7 @@ def main():
         # N > 1, u8 payload: cyclic row ownership (rank r renders patch rows r, r+N, ...: every
         # rank gets its share of cheap sky and expensive ground rows) with the display bytes
         # packed per rank; f64 payload: contiguous equal bands gathered in place.
-        cyclic = world > 1 and args.payload == "u8"
+        cyclic = use_dist and args.payload == "u8"
         if cyclic:
             c_rows, owned = workloads.cyclic_rows(n_rows, world)
             band = (rank, n_rows, world)
@@ -158,7 +198,11 @@ def main():
         pad_h = max(h, world * c_rows * 32)
         # Two frames in flight at N > 1: frame k's collective runs on RCCL's stream while frame
         # k+1 renders (double-buffered), so steady-state throughput is 1 / max(render, gather).
-        n_buf = 2 if use_dist else 1
+        direct = mode["collective"] == "direct" and cyclic
+        if direct and not make_comm(ctx):
+            direct = False
+            mode["collective"], mode["note"] = "torch", "library communicator could not be created on every rank"
+        n_buf = (3 if direct else 2) if use_dist else 1
         frames = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         frames8 = [torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
         frame, frame8 = frames[0], frames8[0]
@@ -179,7 +223,22 @@ def main():
         pending = [None] * n_buf
         counter = [0]
 
-        def step():
+        plain = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)   # the library derives the rank's rows
+        plain.flags = params.flags & 2
+        plain_ref = C.byref(plain)
+        gather_ptrs = [C.c_void_p(g.data_ptr()) for g in gathered]
+        display_ptr = C.c_void_p(display.data_ptr()) if display is not None else None
+
+        def step_direct():
+            """One frame through the library's exchange: render on the slot's own stream, one
+            ncclAllGather on the exchange stream, de-interleave at the consumer; returns at once."""
+            b = counter[0] % n_buf
+            counter[0] += 1
+            st = L.rm_frame_submit(ctx.ptr, plain_ref, frame_ptrs[b], gather_ptrs[b], display_ptr, b)
+            if st != 0:
+                raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
+
+        def step_torch():
             """One frame: render this rank's band (f64 rows + their display bytes), then the
             single collective of the frame (asynchronous: the stream is only made to wait for
             it when its buffer is about to be rendered into again)."""
@@ -198,6 +257,10 @@ def main():
                 pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
 
         def drain():
+            if direct:
+                for b in range(n_buf):
+                    if L.rm_frame_wait(ctx.ptr, b) != 0:
+                        raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
             for i, wk in enumerate(pending):
                 if wk is not None:
                     wk.wait()
@@ -212,6 +275,23 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        if direct:
+            # first frame through both paths: the gathered display bytes must be identical
+            step_torch()
+            fence()
+            want = gathered[0].clone()
+            gathered[0].zero_()
+            counter[0] = 0
+            step_direct()
+            fence()
+            same = torch.tensor([1 if torch.equal(gathered[0], want) else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            counter[0] = 0
+            if int(same.item()) != 1:
+                direct = False
+                ctx.comm_destroy()
+                mode["collective"], mode["note"] = "torch", "library exchange disagreed with the torch path on the check frame"
+        step = step_direct if direct else step_torch
         for _ in range(warmup):
             step()
         # HIP events on the launch stream bracket the timed region (one pair: an event per
@@ -235,6 +315,10 @@ def main():
         # N > 1 the gather's stream time is inside the bracket too, so it is only reported
         # as the kernel's duration at N = 1)
         kernel_ms = ev0.elapsed_time(ev1) / steps
+        if direct:
+            # the frames render on the slots' own streams and overlap: there is no per-launch
+            # duration to bracket; report the per-frame time of the pipeline instead
+            kernel_ms = elapsed / steps * 1e3
         px_launch = n_owned * 32 * w                                        # pixels one launch writes
 
         # the drop-in call itself, rm_render into pageable host memory
@@ -256,6 +340,7 @@ def main():
                     "kernel_ms": tm.kernel_ms, "d2h_ms": tm.d2h_ms,
                     "what": "rm_render(): kernel + device-to-host copy of the f64 frame into pageable memory, median of 10"}
         res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic, host=host,
+                   collective=("direct" if direct else mode["collective"]), frames_in_flight=n_buf,
                    elapsed=elapsed, kernel_ms=kernel_ms, px_launch=px_launch,
                    mpx=(w * h) * steps / elapsed / 1e6,
                    frame=frame, frame8=frame8, display=display)
@@ -305,6 +390,12 @@ def main():
                                    % ("cyclic rows (r, r+N, ...)" if cyclic else "contiguous bands", c_rows, world, (", one in-place RCCL all-gather of the %s rows per frame; "
                                                       "f64 rows stay in each rank's HBM" % args.payload)
                                       if world > 1 else ""),
+                       "collective": {"none": "none (one GPU)",
+                                      "direct": "rm_frame_submit: ncclAllGather from the C library, %d frames in flight, "
+                                                "each rendering on a stream of its own" % r["frames_in_flight"],
+                                      "torch": "torch.distributed.all_gather_into_tensor (%s), %d frames in flight"
+                                               % ("RCCL" if backend == "nccl" else backend, r["frames_in_flight"])}[r["collective"]]
+                                     + (" [%s]" % mode["note"] if mode["note"] else ""),
                        "outputs": "f64 RGB frame [H][W][3] + u8 display frame (to_vec) per launch",
                        "numerics": "fast" if args.fast_fp else "strict (the reference's operations, one rounding each)",
                        "build": L.rm_build_info().decode()},
