@@ -98,3 +98,25 @@ def test_null_arguments_return_status_not_crash(pkg):
     assert L.rm_render_device(None, None, None, None) == E
     assert L.rm_postprocess(None, None, 1, 1, 0, None, None) == E
     assert L.rm_last_error(None) is not None
+
+
+def test_exchange_layout_and_comm_entry_points_without_a_gpu(pkg):
+    """The host-only parts of the multi-GPU frame API: the gather-buffer layout for N ranks
+    (ceil(patch rows / N) rows of 32 * W * 3 bytes per rank) and the argument checks."""
+    L = pkg.lib()
+    E = pkg._lib.RM_ERR_INVALID_ARG
+    rows, chunk = C.c_uint32(0), C.c_size_t(0)
+    for (w, h, world, want_rows) in [(1920, 1080, 1, 33), (1920, 1080, 8, 5), (7680, 4320, 8, 17), (320, 240, 2, 4),
+                                     (4096, 4096, 3, 43), (64, 20, 4, 0)]:
+        p = pkg.backend.make_params(1.5, float(h), float(w), 5)
+        assert L.rm_exchange_layout(C.byref(p), world, C.byref(rows), C.byref(chunk)) == 0
+        assert rows.value == want_rows and chunk.value == want_rows * 32 * w * 3
+    p = pkg.backend.make_params(1.5, 64., 100., 5)
+    assert L.rm_exchange_layout(C.byref(p), 2, None, None) == pkg._lib.RM_ERR_DIMENSIONS
+    assert L.rm_exchange_layout(C.byref(p), 0, None, None) == E
+    assert L.rm_exchange_layout(None, 2, None, None) == E
+    assert L.rm_comm_unique_id(None) == E
+    assert L.rm_comm_init(None, None, 0, 1) == E
+    assert L.rm_frame_submit(None, None, None, None, None, 0) == E
+    assert L.rm_frame_wait(None, 0) == E
+    L.rm_comm_destroy(None)                                     # a no-op, like rm_destroy(NULL)
