@@ -12,6 +12,7 @@ rounding noise (test_resolution_sweep documents them).
 """
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -413,7 +414,7 @@ def test_resolution_sweep(pkg, O, ctx, scene_name):
             compare(gpu, O.render(so, w, h, max_depth=3))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RM_FUZZ_SEEDS", "12"))))   # RM_FUZZ_SEEDS=300: a longer hunt
 def test_fuzz_random_scenes(pkg, O, ctx, seed):
     """Seeded random scenes: spheres (some glass, some coincident), counter-clockwise convex
     polygons, a random-triangle mesh, 1-3 lights, integer and fractional camera positions,
