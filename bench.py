@@ -375,6 +375,11 @@ def main():
                 if pmc.get("config") == args.config and pmc.get("n_gpus", 1) == world:
                     traffic = pmc.get("hbm_bytes_per_launch")
                     valu = {k: pmc.get(k) for k in ("valu_busy_frac", "valu_lanes_active_frac", "valu_wave_instructions")}
+                    if valu["valu_wave_instructions"]:
+                        # the bound that does apply: one 64-lane VALU instruction per SIMD per 4 cycles
+                        # (1024 SIMDs, 2.4 GHz peak clock) against this run's kernel time
+                        valu["valu_issue_frac_of_peak"] = (valu["valu_wave_instructions"] * 4.0
+                                                           / (1024 * 2.4e9 * kernel_ms * 1e-3))
             except Exception:
                 traffic = None
         out = {
