@@ -13,8 +13,8 @@ N > 1: the frame is sharded by 32-row patch rows (cyclic ownership
 renders patch rows r, r+N, ...), and ONE in-place RCCL all-gather per frame, inside the
 timed region, completes the display frame on every rank (--payload u8, default; rank 0 is
 the consumer) or the f64 frame (--payload f64, contiguous bands).  The default exchange is
-the library's own (rm_frame_submit: three frames in flight, each rendering on a stream of
-its own, ncclAllGather issued from C); its first frame is checked byte for byte against
+the library's own (rm_frame_submit: four frames in flight, each on a stream of its own,
+ncclAllGather issued from C); its first frame is checked byte for byte against
 torch.distributed.all_gather_into_tensor, which takes over if they disagree
 (--collective torch selects it outright).  Total work is fixed: "strong" scaling.
 
@@ -202,7 +202,7 @@ def main():
         if direct and not make_comm(ctx):
             direct = False
             mode["collective"], mode["note"] = "torch", "library communicator could not be created on every rank"
-        n_buf = (3 if direct else 2) if use_dist else 1
+        n_buf = (4 if direct else 2) if use_dist else 1   # 3 is slower than 2 or 4 (profiles/r01_slots_cost.txt)
         frames = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         frames8 = [torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
         frame, frame8 = frames[0], frames8[0]
@@ -217,7 +217,9 @@ def main():
         frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
         # cyclic: the kernel packs this rank's display rows straight into its chunk of the gather buffer
         frame8_ptrs = [C.c_void_p((ch if cyclic else f8).data_ptr()) for ch, f8 in zip(my_chunk, frames8)]
-        display = torch.zeros_like(gathered[0]) if cyclic and rank == 0 else None   # image-order frame at the consumer
+        # image-order display frames at the consumer, one per frame in flight
+        displays = [torch.zeros_like(g) for g in gathered] if cyclic and rank == 0 else None
+        display = displays[0] if displays else None
         stream_ptr = C.c_void_p(stream.cuda_stream)
         has_rows = n_owned > 0
         pending = [None] * n_buf
@@ -227,14 +229,14 @@ def main():
         plain.flags = params.flags & 2
         plain_ref = C.byref(plain)
         gather_ptrs = [C.c_void_p(g.data_ptr()) for g in gathered]
-        display_ptr = C.c_void_p(display.data_ptr()) if display is not None else None
+        display_ptrs = [C.c_void_p(d.data_ptr()) for d in displays] if displays else [None] * n_buf
 
         def step_direct():
             """One frame through the library's exchange: render on the slot's own stream, one
             ncclAllGather on the exchange stream, de-interleave at the consumer; returns at once."""
             b = counter[0] % n_buf
             counter[0] += 1
-            st = L.rm_frame_submit(ctx.ptr, plain_ref, frame_ptrs[b], gather_ptrs[b], display_ptr, b)
+            st = L.rm_frame_submit(ctx.ptr, plain_ref, frame_ptrs[b], gather_ptrs[b], display_ptrs[b], b)
             if st != 0:
                 raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
 
@@ -247,8 +249,8 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()                      # stream-ordered; the host does not block
                 pending[b] = None
-                if display is not None:
-                    workloads.deinterleave_rows(gathered[b], world, display)
+                if displays:
+                    workloads.deinterleave_rows(gathered[b], world, displays[b])
             if has_rows:
                 st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], frame8_ptrs[b], stream_ptr)
                 if st != 0:
@@ -265,8 +267,8 @@ def main():
                 if wk is not None:
                     wk.wait()
                     pending[i] = None
-                    if display is not None:
-                        workloads.deinterleave_rows(gathered[i], world, display)
+                    if displays:
+                        workloads.deinterleave_rows(gathered[i], world, displays[i])
 
         def fence():
             drain()
@@ -339,7 +341,37 @@ def main():
             host = {"value": w * h / med / 1e6, "unit": "Mpixels/s", "ms_per_frame": med * 1e3,
                     "kernel_ms": tm.kernel_ms, "d2h_ms": tm.d2h_ms,
                     "what": "rm_render(): kernel + device-to-host copy of the f64 frame into pageable memory, median of 10"}
-        res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic, host=host,
+        # the same frames with four in flight, each on a stream of its own (rm_frame_submit with no
+        # communicator): what a renderer gets that need not wait for frame k before starting
+        # k+1 -- the ramp and drain of one frame fill with the others (four: HIP maps streams onto
+        # four hardware queues, and two slots may land on one).  Not the metric: a step
+        # of the metric is one frame at a time, like the reference's render().
+        piped = None
+        if world == 1 and rank == 0 and not use_dist and cfg_id == args.config and not args.no_sizes:
+            torch.cuda.synchronize()
+            n_slots = 4
+            pf = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_slots)]
+            pg = [torch.zeros((n_rows * 32, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)]
+            p_plain = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+            p_plain.flags = params.flags & 2
+            n_frames = max(steps, 30)
+            for k in range(n_slots * 4 + n_frames):
+                if k == n_slots * 4:
+                    for b in range(n_slots):
+                        ctx.frame_wait(b)
+                    t1 = time.perf_counter()
+                ctx.frame_submit(p_plain, pf[k % n_slots].data_ptr(), pg[k % n_slots].data_ptr(), None, k % n_slots)
+            for b in range(n_slots):
+                ctx.frame_wait(b)
+            dt = time.perf_counter() - t1
+            piped = {"value": w * h * n_frames / dt / 1e6, "unit": "Mpixels/s", "ms_per_step": dt / n_frames * 1e3,
+                     "frames_in_flight": n_slots,
+                     "what": "rm_frame_submit, %d frames, same outputs per frame as the metric" % n_frames}
+            if args.check:
+                piped["identical_to_single_stream_frame"] = bool(torch.equal(pf[0][:n_rows * 32], frame[:n_rows * 32])
+                                                                 and torch.equal(pg[0], frame8[:n_rows * 32]))
+            del pf, pg
+        res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic, host=host, piped=piped,
                    collective=("direct" if direct else mode["collective"]), frames_in_flight=n_buf,
                    elapsed=elapsed, kernel_ms=kernel_ms, px_launch=px_launch,
                    mpx=(w * h) * steps / elapsed / 1e6,
@@ -430,6 +462,8 @@ def main():
             out["speedup_vs_cpu_baseline"] = mpx / out["cpu_baseline"]["value"]
         if r["host"]:
             out["end_to_end_host"] = r["host"]
+        if r["piped"]:
+            out["four_frames_in_flight"] = r["piped"]
         if other:
             out["other_frames"] = other
         json_out.write(json.dumps(out) + "\n")

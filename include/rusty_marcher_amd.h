@@ -265,9 +265,9 @@ rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t frame_width, ui
  * every rank gets its share of cheap sky and expensive ground rows), each rank's f64 rows
  * stay in its own `device_rgb` (a distributed FrameBuffer), and ONE in-place RCCL
  * all-gather per frame completes the display frame (`to_vec` bytes, framebuffer.rs:40-55)
- * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot renders on a
- * stream of its own and the collectives run on one exchange stream in submission order,
- * so every rank must submit the same sequence of frames.
+ * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream of its
+ * own (render, gather, de-interleave in order) and the collectives execute in submission
+ * order, so every rank must submit the same sequence of frames.
  *
  * Bootstrap: rank 0 calls rm_comm_unique_id and hands the RM_COMM_ID_BYTES to the other
  * ranks by any channel (a file, a socket, torch.distributed's store); every rank then
@@ -290,8 +290,8 @@ rm_status rm_exchange_layout(const rm_params *params, int world, uint32_t *rows_
  * device_gather8 (world * chunk_bytes), all-gathers the chunks in place, and -- where
  * device_display8 is not NULL (the consumer, e.g. rank 0's window) -- writes the
  * [32*n_patch_rows][W][3] image-order display frame.  params->patch_row_* must be zero.
- * The buffers belong to `slot` until rm_frame_wait(slot) returns or the slot is submitted
- * again (which orders itself after the slot's previous exchange).
+ * All four buffers belong to `slot` until rm_frame_wait(slot) returns or the slot is
+ * submitted again (a slot's frames are ordered); two slots must not share a buffer.
  */
 rm_status rm_frame_submit(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_gather8,
                           void *device_display8, uint32_t slot);

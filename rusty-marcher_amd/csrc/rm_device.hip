@@ -105,7 +105,7 @@ enum { TILE_ORDER_NATURAL = 0, TILE_ORDER_REVERSE = 1, TILE_ORDER_HASH = 2 };
 // A frame in flight (rm_frame_submit): its own render stream, so that consecutive frames overlap.
 struct rm_frame_slot {
     hipStream_t render = nullptr;
-    hipEvent_t rendered = nullptr, exchanged = nullptr;
+    hipEvent_t exchanged = nullptr;   // recorded after the last operation of the slot's frame
     bool used = false;
 };
 
@@ -144,7 +144,6 @@ struct rm_ctx {
     void *comm = nullptr;             // ncclComm_t
     bool comm_local = false;          // rank/world set without a transport (rm_comm_init with id == NULL)
     int rank = 0, world = 1;
-    hipStream_t xchg_stream = nullptr;
     rm_frame_slot slots[RM_MAX_FRAME_SLOTS];
 
     // post-process scratch
@@ -277,10 +276,8 @@ void rm_destroy(rm_ctx *ctx) {
     rm_comm_destroy(ctx);
     for (rm_frame_slot &s : ctx->slots) {
         if (s.render) { (void)hipStreamSynchronize(s.render); (void)hipStreamDestroy(s.render); }
-        if (s.rendered) (void)hipEventDestroy(s.rendered);
         if (s.exchanged) (void)hipEventDestroy(s.exchanged);
     }
-    if (ctx->xchg_stream) (void)hipStreamDestroy(ctx->xchg_stream);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_max) (void)hipFree(ctx->d_max);
