@@ -102,6 +102,10 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    # Frames in flight run on streams of their own (rm_frame_submit); HIP maps streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4, shared with every other stream of the
+    # process) and two slots on one queue do not overlap.  Must be set before HIP starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
