@@ -259,6 +259,16 @@ rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes);
 rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t frame_width, uint32_t frame_height,
                          int normalize, uint8_t *host_rgb8, double *max_out);
 
+/* ---- device buffers for hosts without HIP bindings -------------------------------------
+ * The device-pointer entry points (rm_render_device*, rm_frame_submit) take plain
+ * hipMalloc'ed pointers; a host that links no HIP runtime of its own (the Rust shim) gets
+ * them here.  rm_buffer_alloc zero-fills (create_frame_buffer does, framebuffer.rs:12-22);
+ * rm_buffer_read is synchronous and does not order itself after work in flight: call it
+ * after rm_frame_wait / on buffers no launch is still writing. */
+rm_status rm_buffer_alloc(rm_ctx *ctx, size_t bytes, void **device_ptr);
+void rm_buffer_free(rm_ctx *ctx, void *device_ptr);
+rm_status rm_buffer_read(rm_ctx *ctx, const void *device_ptr, void *host_dst, size_t bytes);
+
 /* ---- multi-GPU frames: one process per GPU, RCCL over xGMI ----------------------------
  * Replaces, for N GPUs, what renderer.rs:63-108 does with N Rayon workers: the patch rows
  * of a frame are owned cyclically (rank r renders patch rows r, r+N, r+2N, ... so that

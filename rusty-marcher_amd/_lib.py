@@ -107,6 +107,9 @@ SIGNATURES = {
     "rm_render_device_u8": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP]),
     "rm_device_framebuffer": (C.c_int, [_VP, _P(_VP), _P(C.c_size_t)]),
     "rm_postprocess": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_int, _P(C.c_uint8), _P(C.c_double)]),
+    "rm_buffer_alloc": (C.c_int, [_VP, C.c_size_t, _P(_VP)]),
+    "rm_buffer_free": (None, [_VP, _VP]),
+    "rm_buffer_read": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "rm_comm_unique_id": (C.c_int, [_VP]),
     "rm_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "rm_comm_destroy": (None, [_VP]),

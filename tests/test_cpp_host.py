@@ -66,3 +66,45 @@ def test_rm_demo_reproduces_out_ppm(rm_demo, golden_ppm, tmp_path, extra):
 def test_rm_demo_width_panic(rm_demo, tmp_path):
     r = subprocess.run([rm_demo, "--width", "100", "--height", "64", "--out", str(tmp_path / "x.ppm")], capture_output=True)
     assert r.returncode == 101 and b"multiple of 32" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rccl", [True, False])
+def test_rm_walk_camera_walk_matches_oracle(entry, O, tmp_path, rccl):
+    """rm_walk: the interactive loop from compiled code over the C ABI alone (no HIP, no RCCL
+    on the host side) -- camera moves with the scene resident on the device, frames in
+    flight over the slots, rank 0 writes every frame's display bytes.  World of one GPU
+    (with and without a one-rank RCCL communicator, its id published through a file);
+    every frame must be the oracle's to_vec() of the same camera position."""
+    import workloads
+    exe = os.path.join(entry.PKG_DIR, "lib", "rm_walk")
+    if not os.path.exists(exe):
+        entry.build()
+    w, h, depth, frames = 320, 250, 4, 7
+    cmd = [exe, "--rank", "0", "--world", "1", "--frames", str(frames), "--width", str(w), "--height", str(h),
+           "--depth", str(depth), "--step", "0.5,0.25,-1", "--out", str(tmp_path / "walk"),
+           "--id-file", str(tmp_path / "id.bin")] + ([] if rccl else ["--no-rccl"])
+    log = subprocess.check_output(cmd).decode()
+    assert "%d frames on 1 GPU(s)" % frames in log
+    assert os.path.exists(tmp_path / "id.bin") == rccl and (not rccl or os.path.getsize(tmp_path / "id.bin") == 128)
+    rows = h // 32 * 32
+    so = workloads.oracle_scene(O, "demo")
+    for k in range(frames):
+        data = (tmp_path / ("walk_%04d.ppm" % k)).read_bytes()
+        header = b"P6\n%d %d\n255\n" % (w, rows)
+        assert data.startswith(header) and len(data) == len(header) + rows * w * 3
+        so.set_camera((0.5 * k, 0.25 * k, -1. * k))
+        ref = O.to_vec(O.render(so, w, h, max_depth=depth)[:rows].copy())
+        got = np.frombuffer(data[len(header):], np.uint8)
+        assert int((got != ref).sum()) <= 2, "frame %d" % k      # a u8 truncation may flip within an ulp of k/255
+
+
+def test_rm_walk_usage_errors(entry):
+    exe = os.path.join(entry.PKG_DIR, "lib", "rm_walk")
+    if not os.path.exists(exe):
+        entry.build()
+    assert subprocess.run([exe, "--rank", "2", "--world", "2"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "--world", "2", "--rank", "0"], capture_output=True).returncode == 2    # no --id-file
+    assert subprocess.run([exe, "--bogus"], capture_output=True).returncode == 2
+    r = subprocess.run([exe, "--world", "1", "--rank", "0", "--no-rccl"], capture_output=True)          # no GPU here: a panic, not a fallback
+    assert r.returncode in (0, 101)
