@@ -121,6 +121,17 @@ extern "C" {
     fn rm_last_error(ctx: *const RmCtx) -> *const c_char;
     fn rm_scene_upload(ctx: *mut RmCtx, desc: *const RmSceneDesc) -> c_int;
     fn rm_render(ctx: *mut RmCtx, p: *const RmParams, host_rgb: *mut f64, t: *mut RmTiming) -> c_int;
+    // interactive loop / several GPUs (one process per GPU): see host/rm_walk.cpp for the same
+    // sequence in C++ -- rm_camera_update between frames, up to 4 frames in flight
+    #[allow(dead_code)] fn rm_camera_update(ctx: *mut RmCtx, camera: RmVec3) -> c_int;
+    #[allow(dead_code)] fn rm_buffer_alloc(ctx: *mut RmCtx, bytes: usize, device_ptr: *mut *mut c_void) -> c_int;
+    #[allow(dead_code)] fn rm_buffer_free(ctx: *mut RmCtx, device_ptr: *mut c_void);
+    #[allow(dead_code)] fn rm_buffer_read(ctx: *mut RmCtx, device_ptr: *const c_void, host_dst: *mut c_void, bytes: usize) -> c_int;
+    #[allow(dead_code)] fn rm_comm_unique_id(id_out: *mut c_void) -> c_int; // 128 bytes
+    #[allow(dead_code)] fn rm_comm_init(ctx: *mut RmCtx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    #[allow(dead_code)] fn rm_exchange_layout(p: *const RmParams, world: c_int, rows_per_rank: *mut u32, chunk_bytes: *mut usize) -> c_int;
+    #[allow(dead_code)] fn rm_frame_submit(ctx: *mut RmCtx, p: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, slot: u32) -> c_int;
+    #[allow(dead_code)] fn rm_frame_wait(ctx: *mut RmCtx, slot: u32) -> c_int;
 }
 
 /// The reference's failure mode on this path is a panic.
