@@ -120,3 +120,6 @@ def test_exchange_layout_and_comm_entry_points_without_a_gpu(pkg):
     assert L.rm_frame_submit(None, None, None, None, None, 0) == E
     assert L.rm_frame_wait(None, 0) == E
     L.rm_comm_destroy(None)                                     # a no-op, like rm_destroy(NULL)
+    assert L.rm_buffer_alloc(None, 16, None) == E
+    assert L.rm_buffer_read(None, None, None, 0) == E
+    L.rm_buffer_free(None, None)
