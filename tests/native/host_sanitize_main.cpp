@@ -1,5 +1,6 @@
 // AddressSanitizer / UBSan exercise of the host half of the C ABI (csrc/rm_scene.cpp):
-// scene builder, OBJ ingest (good and malformed files), status formatting.  CPU only.
+// scene builder, OBJ ingest (good and malformed files), status formatting, and the
+// hierarchy builder the upload uses (csrc/rm_bvh.hpp).  CPU only.
 #include <cassert>
 #include <cstdio>
 #include <cstring>
@@ -8,10 +9,59 @@
 
 #include "rusty_marcher_amd.h"
 #include "rm_internal.h"
+#include "rm_bvh.hpp"
 
 // the device half (rm_device.hip) is not part of this CPU-only build: its one symbol the
 // host half's callers need is the error accessor
 extern "C" const char *rm_last_error(const rm_ctx *) { return rm_get_host_error(); }
+
+// rm_build_bvh invariants the kernel's walk relies on: `order` is a permutation; every leaf
+// holds 1..leaf_size consecutive primitives and every primitive sits in exactly one leaf;
+// a child box contains the boxes of everything below it (with the builder's inflation).
+static void walk_hierarchy(const rm_bvh &h, const std::vector<rm_aabb> &boxes, uint64_t ref, const double *box,
+                           uint32_t leaf_size, std::vector<int> &seen, int depth) {
+    assert(depth < 64);
+    const uint32_t idx = (uint32_t)ref, cnt = (uint32_t)(ref >> 32);
+    if (cnt) {                                                          // leaf
+        assert(cnt <= leaf_size && (size_t)idx + cnt <= boxes.size());
+        for (uint32_t k = 0; k < cnt; k++) {
+            const rm_aabb &b = boxes[h.order[idx + k]];
+            seen[idx + k]++;
+            for (int a = 0; a < 3; a++) assert(box[a] <= b.lo[a] && b.hi[a] <= box[3 + a]);
+        }
+        return;
+    }
+    assert((size_t)(idx + 1) * RM_BVH_NODE_WORDS <= h.nodes.size());
+    const double *n = &h.nodes[(size_t)idx * RM_BVH_NODE_WORDS];
+    uint64_t l, r;
+    std::memcpy(&l, &n[12], 8);
+    std::memcpy(&r, &n[13], 8);
+    for (int a = 0; a < 3; a++) {                                       // children inside the parent (root: no parent box)
+        if (box) { assert(box[a] <= n[a] + 1e-6 && n[3 + a] <= box[3 + a] + 1e-6); assert(box[a] <= n[6 + a] + 1e-6 && n[9 + a] <= box[3 + a] + 1e-6); }
+        assert(n[a] <= n[3 + a] && n[6 + a] <= n[9 + a]);
+    }
+    walk_hierarchy(h, boxes, l, n, leaf_size, seen, depth + 1);
+    walk_hierarchy(h, boxes, r, n + 6, leaf_size, seen, depth + 1);
+}
+
+static void check_hierarchy(uint32_t n_prims, uint32_t leaf_size) {
+    std::vector<rm_aabb> boxes(n_prims);
+    uint64_t state = 0x9E3779B97F4A7C15ull * (n_prims + 1);
+    auto rnd = [&]() { state = state * 6364136223846793005ull + 1442695040888963407ull; return (double)(state >> 11) / 9007199254740992.; };
+    for (rm_aabb &b : boxes)
+        for (int a = 0; a < 3; a++) {
+            const double c = (n_prims % 2 ? 0. : 100. * rnd() - 50.), e = 2. * rnd();   // odd counts: all coincident centres
+            b.lo[a] = c - e; b.hi[a] = c + e;
+        }
+    if (n_prims <= leaf_size) return;                                   // the upload never builds one over so few
+    const rm_bvh h = rm_build_bvh(boxes, leaf_size);
+    assert(h.order.size() == n_prims && h.nodes.size() % RM_BVH_NODE_WORDS == 0 && !h.nodes.empty());
+    std::vector<int> perm(n_prims, 0), seen(n_prims, 0);
+    for (uint32_t o : h.order) { assert(o < n_prims); perm[o]++; }
+    for (int c : perm) assert(c == 1);
+    walk_hierarchy(h, boxes, 0, nullptr, leaf_size, seen, 0);           // ref 0 = inner node 0, the root
+    for (int c : seen) assert(c == 1);
+}
 
 int main(int argc, char **argv) {
     assert(argc >= 3);
@@ -74,6 +124,11 @@ int main(int argc, char **argv) {
         else assert(std::strlen(rm_last_error(nullptr)) > 0);
         rm_scene_free(b);
     }
+    check_hierarchy(1, 4);
+    check_hierarchy(5, 4);
+    check_hierarchy(257, 4);
+    check_hierarchy(1000, 2);
+    check_hierarchy(64, 1);
     char buf[8];
     assert(rm_format_status(buf, sizeof buf, 92, 1280, 800) > 7);   // truncated, NUL-terminated
     assert(buf[7] == '\0');
