@@ -55,6 +55,9 @@ int main(int argc, char **argv) {
     if (world > 1 && id_file.empty()) { std::fprintf(stderr, "--world > 1 needs --id-file\n"); return 2; }
     if (device < 0) device = rank;                              // one GPU per rank
 
+    // each frame slot has a stream of its own; HIP's default of 4 hardware queues would make
+    // slots share one and serialise (profiles/r01_slots_cost.txt).  Read when HIP starts.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     rm_ctx *ctx = nullptr;
     CHECK(nullptr, rm_init(device, &ctx));
     rm_scene *scene = nullptr;
