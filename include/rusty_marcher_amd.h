@@ -275,9 +275,9 @@ rm_status rm_buffer_read(rm_ctx *ctx, const void *device_ptr, void *host_dst, si
  * every rank gets its share of cheap sky and expensive ground rows), each rank's f64 rows
  * stay in its own `device_rgb` (a distributed FrameBuffer), and ONE in-place RCCL
  * all-gather per frame completes the display frame (`to_vec` bytes, framebuffer.rs:40-55)
- * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream of its
- * own (render, gather, de-interleave in order) and the collectives execute in submission
- * order, so every rank must submit the same sequence of frames.
+ * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream and a
+ * communicator of its own (render, gather, de-interleave in order on the stream); every rank
+ * must submit the same sequence of (frame, slot) pairs.
  *
  * Bootstrap: rank 0 calls rm_comm_unique_id and hands the RM_COMM_ID_BYTES to the other
  * ranks by any channel (a file, a socket, torch.distributed's store); every rank then

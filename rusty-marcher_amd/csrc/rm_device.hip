@@ -142,6 +142,7 @@ struct rm_ctx {
 
     // multi-GPU frames (rm_exchange.inc)
     void *comm = nullptr;             // ncclComm_t
+    void *slot_comm[RM_MAX_FRAME_SLOTS] = {};   // per frame slot: communicators split off `comm` (or `comm` itself)
     bool comm_local = false;          // rank/world set without a transport (rm_comm_init with id == NULL)
     int rank = 0, world = 1;
     rm_frame_slot slots[RM_MAX_FRAME_SLOTS];
