@@ -237,7 +237,7 @@ def main():
 
         def step_direct():
             """One frame through the library's exchange: render on the slot's own stream, one
-            ncclAllGather on the exchange stream, de-interleave at the consumer; returns at once."""
+            ncclAllGather and the de-interleave at the consumer behind it on the same stream; returns at once."""
             b = counter[0] % n_buf
             counter[0] += 1
             st = L.rm_frame_submit(ctx.ptr, plain_ref, frame_ptrs[b], gather_ptrs[b], display_ptrs[b], b)
