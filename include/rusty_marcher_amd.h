@@ -268,6 +268,10 @@ rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t frame_width, ui
 rm_status rm_buffer_alloc(rm_ctx *ctx, size_t bytes, void **device_ptr);
 void rm_buffer_free(rm_ctx *ctx, void *device_ptr);
 rm_status rm_buffer_read(rm_ctx *ctx, const void *device_ptr, void *host_dst, size_t bytes);
+/* Page-locked host memory: the destination rm_frame_submit can copy a finished display
+ * frame into asynchronously (a pageable destination would make the copy synchronous). */
+rm_status rm_host_alloc(rm_ctx *ctx, size_t bytes, void **host_ptr);
+void rm_host_free(rm_ctx *ctx, void *host_ptr);
 
 /* ---- multi-GPU frames: one process per GPU, RCCL over xGMI ----------------------------
  * Replaces, for N GPUs, what renderer.rs:63-108 does with N Rayon workers: the patch rows
@@ -305,6 +309,11 @@ rm_status rm_exchange_layout(const rm_params *params, int world, uint32_t *rows_
  */
 rm_status rm_frame_submit(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_gather8,
                           void *device_display8, uint32_t slot);
+/* The same, and the display frame is then copied into host_display8 (rm_host_alloc'ed,
+ * 32 * n_patch_rows * W * 3 bytes) on the slot's stream: after rm_frame_wait(slot) the bytes
+ * of fb.to_vec() are in host memory (main.rs:337-346 hands them to the pixbuf). */
+rm_status rm_frame_submit_to_host(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_gather8,
+                                  void *device_display8, void *host_display8, uint32_t slot);
 /* Blocks the host until the slot's last frame is complete on this rank. */
 rm_status rm_frame_wait(rm_ctx *ctx, uint32_t slot);
 

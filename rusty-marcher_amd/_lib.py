@@ -110,6 +110,9 @@ SIGNATURES = {
     "rm_buffer_alloc": (C.c_int, [_VP, C.c_size_t, _P(_VP)]),
     "rm_buffer_free": (None, [_VP, _VP]),
     "rm_buffer_read": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "rm_host_alloc": (C.c_int, [_VP, C.c_size_t, _P(_VP)]),
+    "rm_host_free": (None, [_VP, _VP]),
+    "rm_frame_submit_to_host": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP, _VP, C.c_uint32]),
     "rm_comm_unique_id": (C.c_int, [_VP]),
     "rm_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "rm_comm_destroy": (None, [_VP]),

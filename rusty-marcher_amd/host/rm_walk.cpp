@@ -9,7 +9,8 @@
 // Rank 0 creates the RCCL unique id and publishes it through PATH (written to PATH.tmp,
 // then renamed); the other ranks wait for the file.  Every rank renders its cyclic share
 // of every frame; rank 0, the consumer, receives the display bytes of the whole frame and
-// writes PREFIX_%04d.ppm (the bytes of fb.to_vec(), not normalised -- what the UI blits).
+// (copied to page-locked host memory as part of the frame) and writes PREFIX_%04d.ppm (the
+// bytes of fb.to_vec(), not normalised -- what the UI blits).
 // --world 1 needs no file: the single rank still goes through RCCL unless --no-rccl.
 #include <chrono>
 #include <cstdio>
@@ -111,20 +112,21 @@ int main(int argc, char **argv) {
         CHECK(ctx, rm_buffer_alloc(ctx, chunk * (size_t)world, &d_gather[s]));
         if (rank == 0) CHECK(ctx, rm_buffer_alloc(ctx, display_bytes, &d_display[s]));
     }
-    std::vector<unsigned char> host(rank == 0 ? display_bytes : 0);
+    std::vector<void *> host(n_slots, nullptr);                 // page-locked: the copy of a finished frame is asynchronous
+    if (rank == 0)
+        for (uint32_t s = 0; s < n_slots; s++) CHECK(ctx, rm_host_alloc(ctx, display_bytes, &host[s]));
     std::vector<int> frame_in_slot(n_slots, -1);
 
     auto consume = [&](uint32_t s) {                            // the consumer's side of a finished slot
         CHECK(ctx, rm_frame_wait(ctx, s));
         if (rank != 0 || frame_in_slot[s] < 0) return;
-        CHECK(ctx, rm_buffer_read(ctx, d_display[s], host.data(), display_bytes));
         if (!out.empty()) {
             char name[512];
             std::snprintf(name, sizeof name, "%s_%04d.ppm", out.c_str(), frame_in_slot[s]);
             FILE *f = std::fopen(name, "wb");
             if (!f) { std::fprintf(stderr, "cannot write %s\n", name); std::exit(1); }
             std::fprintf(f, "P6\n%u %u\n255\n", width, (unsigned)(n_patch_rows * 32u));   // framebuffer.rs:26-38 header
-            std::fwrite(host.data(), 1, display_bytes, f);
+            std::fwrite(host[s], 1, display_bytes, f);
             std::fclose(f);
         }
     };
@@ -135,7 +137,7 @@ int main(int argc, char **argv) {
         const uint32_t s = k % n_slots;
         if (frame_in_slot[s] >= 0) consume(s);                  // frame k - n_slots: display it before its buffers are reused
         CHECK(ctx, rm_camera_update(ctx, cam));                 // main.rs:75-78: the camera moves, the scene stays on the device
-        CHECK(ctx, rm_frame_submit(ctx, &p, d_rgb[s], d_gather[s], d_display[s], s));
+        CHECK(ctx, rm_frame_submit_to_host(ctx, &p, d_rgb[s], d_gather[s], d_display[s], host[s], s));
         frame_in_slot[s] = (int)k;
         cam.x += step.x; cam.y += step.y; cam.z += step.z;
     }
@@ -151,6 +153,7 @@ int main(int argc, char **argv) {
         rm_buffer_free(ctx, d_rgb[s]);
         rm_buffer_free(ctx, d_gather[s]);
         rm_buffer_free(ctx, d_display[s]);
+        rm_host_free(ctx, host[s]);
     }
     rm_scene_free(scene);
     rm_destroy(ctx);

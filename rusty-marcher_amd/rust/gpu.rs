@@ -131,6 +131,9 @@ extern "C" {
     #[allow(dead_code)] fn rm_comm_init(ctx: *mut RmCtx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
     #[allow(dead_code)] fn rm_exchange_layout(p: *const RmParams, world: c_int, rows_per_rank: *mut u32, chunk_bytes: *mut usize) -> c_int;
     #[allow(dead_code)] fn rm_frame_submit(ctx: *mut RmCtx, p: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, slot: u32) -> c_int;
+    #[allow(dead_code)] fn rm_host_alloc(ctx: *mut RmCtx, bytes: usize, host_ptr: *mut *mut c_void) -> c_int;
+    #[allow(dead_code)] fn rm_host_free(ctx: *mut RmCtx, host_ptr: *mut c_void);
+    #[allow(dead_code)] fn rm_frame_submit_to_host(ctx: *mut RmCtx, p: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, host_display8: *mut c_void, slot: u32) -> c_int;
     #[allow(dead_code)] fn rm_frame_wait(ctx: *mut RmCtx, slot: u32) -> c_int;
 }
 
