@@ -123,3 +123,6 @@ def test_exchange_layout_and_comm_entry_points_without_a_gpu(pkg):
     assert L.rm_buffer_alloc(None, 16, None) == E
     assert L.rm_buffer_read(None, None, None, 0) == E
     L.rm_buffer_free(None, None)
+    assert L.rm_host_alloc(None, 16, None) == E
+    L.rm_host_free(None, None)
+    assert L.rm_frame_submit_to_host(None, None, None, None, None, None, 0) == E
