@@ -464,7 +464,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     if (H.off_bvh_triangles) std::memcpy(&blob[H.off_bvh_triangles], bvh_t.nodes.data(), bvh_t.nodes.size() * sizeof(double));
 
     RM_HIP(ctx, hipSetDevice(ctx->device));
-    RM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a render may still be reading the old blob
+    RM_HIP(ctx, hipDeviceSynchronize());   // a render (on any stream: the caller's, a frame slot's) may still be reading the old blob
     if (ctx->d_scene_words < blob.size()) {
         if (ctx->d_scene) RM_HIP(ctx, hipFree(ctx->d_scene));
         ctx->d_scene = nullptr;
