@@ -1,61 +1,217 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the render hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py                                   one GPU
+    python bench.py --gpus N --steps K --warmup W     N GPUs: starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      (the same under a launcher)
 
-A step is one frame of the workload: BASELINE.json's configs[1] (demo scene,
-1920x1080, depth cap 5) unless --config says otherwise.  Each launch writes the f64 RGB
-frame (the reference's FrameBuffer) and its display bytes (`to_vec`, what the UI blits)
-to HBM; inputs (the scene) are uploaded before the timed region.
+A step is one frame of the workload: BASELINE.json's configs[1] (demo scene, 1920x1080,
+depth cap 5) unless --config says otherwise.  Each launch writes the f64 RGB frame (the
+reference's FrameBuffer) and its display bytes (`to_vec`, what the UI blits) to HBM; inputs
+(the scene) are uploaded before the timed region.
+
 N > 1: the frame is sharded by 32-row patch rows (cyclic ownership: rank r
-renders patch rows r, r+N, ...), and ONE in-place RCCL all-gather per frame, inside the
-timed region, completes the display frame on every rank (--payload u8, default; rank 0 is
-the consumer) or the f64 frame (--payload f64, contiguous bands).  The default exchange is
-the library's own (rm_frame_submit: four frames in flight, each on a stream of its own,
-ncclAllGather issued from C); its first frame is checked byte for byte against
-torch.distributed.all_gather_into_tensor, which takes over if they disagree
-(--collective torch selects it outright).  Total work is fixed: "strong" scaling.
+renders patch rows r, r+N, ...) and ONE in-place RCCL all-gather per frame, inside the timed
+region, completes the display frame on every rank (--payload u8, the default; rank 0 is the
+consumer) or the f64 frame itself (--payload f64).  Two exchanges are measured, in this
+order, K steps each:
+  1. torch.distributed.all_gather_into_tensor per frame (two frames in flight) -- its
+     numbers are kept whatever happens next;
+  2. the library's own exchange (rm_frame_submit / rm_frame_submit_f64: four frames in
+     flight, each on a stream of its own, ncclAllGather issued from C), first checked byte for
+     byte against (1), every wait bounded (RM_ERR_TIMEOUT, never a hang).
+`value` is the faster of the two when (2) completed and agreed, else (1)'s; the line says
+which and carries both.  Total work is fixed: "strong" scaling.
+
+Started with --gpus N > 1 and no launcher (WORLD_SIZE unset), this file starts the N rank
+processes itself -- before anything touches a GPU -- relays rank 0's JSON line and enforces a
+deadline: a run that hangs is killed (by process group) and reported, never waited for.
 
 Rank 0 prints ONE JSON line.  Metric definition follows the reference
 (renderer.rs:113-120): frame_width x frame_height pixels per frame / wall time.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PIXEL = 24            # 3 x f64 written per pixel (framebuffer.rs Vec3f), SURVEY.md 8d
+WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
 
 
-def cpu_baseline(O, workloads, cfg, budget_s=12.0):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C2", help="workload id from workloads.CONFIGS")
+    ap.add_argument("--payload", choices=["u8", "f64"], default="u8",
+                    help="what the per-frame all-gather moves at N > 1: the display bytes (to_vec, 3 B/px) "
+                         "or the f64 rows themselves (24 B/px)")
+    ap.add_argument("--collective", choices=["direct", "torch"], default="direct",
+                    help="N > 1: 'direct' = measure the torch all-gather path, then the library's own frame exchange "
+                         "(rm_frame_submit*) and report the latter when it completes and agrees; 'torch' = the torch path only")
+    ap.add_argument("--fast-fp", action="store_true",
+                    help="RM_FLAG_FAST_FP flavour of the kernel (FMA, Newton rsqrt): faster, but may decide "
+                         "exact-incidence pixels differently from the reference -- not the parity configuration")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the per-frame collective even at world size 1 (smoke test of the N > 1 code path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true",
+                    help="skip the extras reported beside the metric (other configs, rm_render into host memory)")
+    ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
+    ap.add_argument("--deadline", type=float, default=900.,
+                    help="self-spawned runs (--gpus N > 1 without a launcher): seconds after which the rank processes are killed")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the ranks rendezvous over gloo and go through the step / barrier / max-over-ranks / JSON "
+                         "plumbing with an empty step; prints a line marked dry_run with value null (CPU test of the spawn path)")
+    ap.add_argument("--dry-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)   # test hook: this rank never finishes
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------
+# self-spawn: N rank processes, started before this process has touched a GPU
+# ------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _kill_group(proc):
+    """Ends exactly the process group this launcher started (never a pattern)."""
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        if proc.poll() is not None:
+            return
+        try:
+            os.killpg(proc.pid, sig)
+        except ProcessLookupError:
+            return
+        try:
+            proc.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            pass
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start N copies of this file (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment), relay rank 0's JSON line, return the exit
+    code.  Nothing here initialises a GPU: torch.cuda.device_count() only counts."""
+    n = args.gpus
+    if not args.dry_run and os.environ.get("RM_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d needs %d GPUs; this node shows %d\n" % (n, n, have))
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    partial = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rm_bench_partial_%d.json" % os.getpid())
+    env["RM_BENCH_PARTIAL"] = partial
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().decode().splitlines()), daemon=True)
+    reader.start()
+    t_end = time.time() + args.deadline
+    why = None
+    while any(p.poll() is None for p in procs):
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed and why is None:
+            why = "rank %d exited with code %d" % (procs.index(failed[0]), failed[0].returncode)
+            t_end = min(t_end, time.time() + 30.)          # the others get half a minute to notice
+        if time.time() > t_end:
+            why = why or "deadline of %.0f s reached" % args.deadline
+            for p in procs:
+                _kill_group(p)
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    line = next((ln for ln in reversed(lines) if ln.startswith("{")), None)
+    rc = next((c for c in codes if c), 0)
+    if line is None:
+        # no number: say why, with whatever rank 0 had measured before it stopped
+        part = None
+        try:
+            part = json.load(open(partial))
+        except Exception:
+            pass
+        line = json.dumps({"metric": "Mpixels/sec at 1920x1080, max-bounce=5", "value": None, "unit": "Mpixels/s",
+                           "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "error": why or "no output from rank 0",
+                           "rank_exit_codes": codes, "partial": part})
+        rc = rc or 5
+    try:
+        os.remove(partial)
+    except OSError:
+        pass
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    if why:
+        sys.stderr.write("bench.py: %s (rank exit codes %s)\n" % (why, codes))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def csrc_hash():
+    """sha256 over the kernel sources: ties profiles/pmc_latest.json to a build."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rusty-marcher_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".hpp", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(O, workloads, cfg, budget_s=25.0):
     """The oracle driven like renderer.rs:63-108 (dynamic 32x32 patches over all host
-    threads, per-patch buffers, serial scatter), timed on a bounded sample: whole frames
-    of the same workload until ~budget_s of wall time or 12 frames."""
+    threads, per-patch buffers, serial scatter), timed on a bounded sample: 3 warm-up frames,
+    then whole frames of the same workload until 20 frames or ~budget_s of wall time."""
+    import numpy as np
     scene = workloads.oracle_scene(O, cfg["scene"])
     w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
     cores = O.lib().orc_online_cpus()
     # large frames: render a band sample instead of whole frames
     n_rows = h // 32
     rows = n_rows
-    est_px_per_s = 3.0e6 * cores if cfg["scene"] == "demo" else 2.0e5 * cores
-    while rows > 1 and (rows * 32 * w) / est_px_per_s > budget_s / 3:
+    est_px_per_s = 1.5e6 * cores if cfg["scene"] == "demo" else 2.0e5 * cores
+    while rows > 1 and 23 * (rows * 32 * w) / est_px_per_s > budget_s:
         rows //= 2
     band = ((n_rows - rows) // 2, (n_rows - rows) // 2 + rows)
     frame = np.zeros((h, w, 3), dtype=np.float64)
-    O.render(scene, w, h, max_depth=depth, frame=frame, band=band)      # warm-up
-    times = []
     t_all = time.perf_counter()
-    while len(times) < 12 and (time.perf_counter() - t_all) < budget_s:
+    for _ in range(3):                                                  # warm-up
+        O.render(scene, w, h, max_depth=depth, frame=frame, band=band)
+    times = []
+    while len(times) < 20 and (len(times) < 5 or (time.perf_counter() - t_all) < budget_s):
         t0 = time.perf_counter()
         O.render(scene, w, h, max_depth=depth, frame=frame, band=band)
         times.append(time.perf_counter() - t0)
@@ -64,37 +220,69 @@ def cpu_baseline(O, workloads, cfg, budget_s=12.0):
     px = w * h if rows == n_rows else rows * 32 * w
     ms = int(med * 1000)
     return {
-        "value": px / med / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
-        "sample": "%d frame(s) of patch rows [%d,%d) of %dx%d %s depth %d, median of %d; "
-                  "oracle (-O2, no fast-math) on pthreads, dynamic 32x32 patches + serial scatter"
-                  % (len(times), band[0], band[1], w, h, cfg["scene"], depth, len(times)),
+        "value": px / med / 1e6, "unit": "Mpixels/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+        "sample": "%d frame(s) of patch rows [%d,%d) of %dx%d %s depth %d after 3 warm-up frames, median; "
+                  "oracle (-O2, no fast-math) on %d pthreads, dynamic 32x32 patches + serial scatter"
+                  % (len(times), band[0], band[1], w, h, cfg["scene"], depth, cores),
         "message": O.status_message(ms, w, h) if rows == n_rows else None,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C2", help="workload id from workloads.CONFIGS")
-    ap.add_argument("--payload", choices=["u8", "f64"], default="u8",
-                    help="what the per-frame all-gather moves at N > 1: the display bytes (to_vec, 3 B/px) "
-                         "or the f64 rows (24 B/px)")
-    ap.add_argument("--collective", choices=["direct", "torch"], default="direct",
-                    help="N > 1, u8 payload: 'direct' = the library's own frame exchange (rm_frame_submit: frames in "
-                         "flight on their own streams, ncclAllGather called from C; checked against the torch path "
-                         "on the first frame, falls back to it on any disagreement); 'torch' = "
-                         "torch.distributed.all_gather_into_tensor per frame")
-    ap.add_argument("--fast-fp", action="store_true",
-                    help="RM_FLAG_FAST_FP flavour of the kernel (FMA, Newton rsqrt): faster, but may decide "
-                         "exact-incidence pixels differently from the reference -- not the parity configuration")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise RCCL and run the per-frame collective even at world size 1 (smoke test of the N > 1 code path)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sizes", action="store_true", help="skip the extras reported beside the metric (4K / 8K frames, rm_render into host memory)")
-    ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------
+def dry_main(args):
+    """--dry-run: the multi-process plumbing with an empty step (gloo, no GPU)."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    import workloads
+    cfg = workloads.CONFIGS[args.config]
+    n_rows = cfg["height"] // 32
+    c_rows, owned = workloads.cyclic_rows(n_rows, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pass
+    fence()
+    if rank == args.dry_hang_rank:
+        while True:                                           # test hook: a rank that never reaches the barrier
+            time.sleep(1.)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rows = torch.tensor([len(owned[rank])], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(rows)
+    if rank == 0:
+        print(json.dumps({"metric": "Mpixels/sec at 1920x1080, max-bounce=5", "value": None, "unit": "Mpixels/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3,
+                          "config": {"workload": args.config, "patch_rows_owned_by_all_ranks": int(rows.item()),
+                                     "patch_rows": n_rows, "rows_per_rank": c_rows}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------
+def rank_main(args):
+    import datetime
+
+    import numpy as np
 
     # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when its
     # communicator comes up, so everything else in this process goes to stderr.
@@ -106,6 +294,8 @@ def main():
     # GPU_MAX_HW_QUEUES hardware queues (default 4, shared with every other stream of the
     # process) and two slots on one queue do not overlap.  Must be set before HIP starts.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # every wait of the library's frame exchange is bounded (rm_frame_wait -> RM_ERR_TIMEOUT)
+    os.environ.setdefault("RM_FRAME_TIMEOUT_MS", "30000")
     import torch
     import torch.distributed as dist
 
@@ -115,8 +305,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start bench.py with --gpus equal to the launcher's rank count "
+                         "(or without a launcher: it starts its own ranks)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     # (RM_BENCH_BACKEND=gloo with every rank on GPU 0 is a dry run of the N > 1 code path on
@@ -124,26 +315,36 @@ def main():
     backend = os.environ.get("RM_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d needs GPU %d; this node shows %d" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        # a collective that never completes ends the rank (torch's watchdog) instead of hanging it
+        tmo = datetime.timedelta(seconds=120)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     pkg = G.load_package()
     L = pkg.lib()
+    partial_path = os.environ.get("RM_BENCH_PARTIAL") if rank == 0 else None
+    partial = {}
 
-    # How the frames are exchanged at N > 1 (decided once, the same on every rank).
-    mode = {"collective": "none", "note": None}
-    if use_dist:
-        mode["collective"] = "torch"
-        if args.collective == "direct" and args.payload == "u8" and backend == "nccl":
-            mode["collective"] = "direct"
+    def note_partial(key, value):
+        """What rank 0 has measured so far, for the launcher to report if the run dies later."""
+        if partial_path:
+            partial[key] = value
+            with open(partial_path + ".tmp", "w") as f:
+                json.dump(partial, f)
+            os.replace(partial_path + ".tmp", partial_path)
+
+    want_direct = use_dist and args.collective == "direct" and backend == "nccl"
+    state = {"direct_note": None}
 
     def make_comm(ctx):
         """RCCL communicator of the library's own frame exchange; the unique id travels
@@ -159,7 +360,7 @@ def main():
         if ids[0] is not None:
             try:
                 ctx.comm_init(rank, world, ids[0])
-                ok = 1
+                ok = 1 if ctx.comm_info()[:2] == (rank, world) else 0
             except Exception as e:                     # noqa: BLE001
                 sys.stderr.write("rank %d: rm_comm_init failed: %s\n" % (rank, e))
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
@@ -169,172 +370,210 @@ def main():
             return False
         return True
 
-    def run_workload(cfg_id, steps, warmup):
-        """Warm-up, then `steps` frames of one workload between fences; returns the
-        timings and what rank 0 holds afterwards."""
+    def run_workload(cfg_id, steps, warmup, extras=False):
+        """Warm-up, then `steps` frames of one workload between fences -- at N > 1 once per
+        exchange path; returns the timings and what rank 0 holds afterwards."""
         cfg = workloads.CONFIGS[cfg_id]
         w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
         n_rows = h // 32
-        # N > 1, u8 payload: cyclic row ownership (rank r renders patch rows r, r+N, ...: every
-        # rank gets its share of cheap sky and expensive ground rows) with the display bytes
-        # packed per rank; f64 payload: contiguous equal bands gathered in place.
-        cyclic = use_dist and args.payload == "u8"
-        if cyclic:
-            c_rows, owned = workloads.cyclic_rows(n_rows, world)
-            band = (rank, n_rows, world)
-            n_owned = len(owned[rank])
-        else:
-            c_rows, bands = workloads.equal_bands(n_rows, world)
-            band = bands[rank]
-            n_owned = band[1] - band[0]
+        unit = 8 if args.payload == "f64" else 1
+        # N > 1: cyclic row ownership (rank r renders patch rows r, r+N, ...: every rank gets its
+        # share of cheap sky and expensive ground rows); the payload rows are packed per rank.
+        cyclic = use_dist
+        c_rows, owned = workloads.cyclic_rows(n_rows, world)
+        band = (rank, n_rows, world) if cyclic else (0, n_rows)
+        n_owned = len(owned[rank])
 
         ctx = pkg.backend.Context(local_rank)
         scene = workloads.product_scene(pkg, cfg["scene"])
         ctx.upload(scene.flatten())
+        fast_flag = 2 if args.fast_fp else 0                                # RM_FLAG_FAST_FP
         params = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
-        if args.fast_fp:
-            params.flags |= 2                                              # RM_FLAG_FAST_FP
-        if cyclic:
-            params.flags |= 4                                              # RM_FLAG_U8_COMPACT
-        # Per rank: the f64 frame (create_frame_buffer zero-fills; this rank's band of it is
-        # rendered, the FrameBuffer is distributed over the ranks' HBM) and the display frame
-        # (u8, `to_vec`), padded to world * c patch rows so the bands all-gather in place.
-        pad_h = max(h, world * c_rows * 32)
-        # Two frames in flight at N > 1: frame k's collective runs on RCCL's stream while frame
-        # k+1 renders (double-buffered), so steady-state throughput is 1 / max(render, gather).
-        direct = mode["collective"] == "direct" and cyclic
-        if direct and not make_comm(ctx):
-            direct = False
-            mode["collective"], mode["note"] = "torch", "library communicator could not be created on every rank"
-        n_buf = (4 if direct else 2) if use_dist else 1   # 3 is slower than 2 or 4 (profiles/r01_slots_cost.txt)
-        frames = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
-        frames8 = [torch.zeros((pad_h, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-        frame, frame8 = frames[0], frames8[0]
-        gathered = [(f8 if args.payload == "u8" else f)[:world * c_rows * 32] for f, f8 in zip(frames, frames8)]
-        my_chunk = [g[rank * c_rows * 32:(rank + 1) * c_rows * 32] for g in gathered]   # views built once
-        # A dedicated stream: the kernel, the timing events and the RCCL op are all ordered
+        params.flags = fast_flag | ((8 if unit == 8 else 4) if cyclic else 0)   # RM_FLAG_F64_COMPACT / RM_FLAG_U8_COMPACT
+        plain = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)   # the library derives the rank's rows
+        plain.flags = fast_flag
+        kernel_name = ctx.kernel_name(params)
+        pad_rows = max(n_rows, world * c_rows) * 32
+
+        n_buf_torch = 2 if use_dist else 1
+        n_buf = 4 if use_dist else 1                      # 3 slots are slower than 2 or 4 (profiles/r01_slots_cost.txt)
+        # Per frame in flight: the f64 frame (create_frame_buffer zero-fills; u8 payload: this
+        # rank's rows of it, the FrameBuffer is distributed over the ranks' HBM), the gather
+        # buffer of the payload (world * c patch rows, rank-major chunks) and, at the consumer,
+        # the payload in image order.
+        frames = [torch.zeros((max(h, pad_rows), w, 3), dtype=torch.float64, device=dev) for _ in range(n_buf)]
+        pay_dtype = torch.float64 if unit == 8 else torch.uint8
+        gathered = [torch.zeros((world * c_rows * 32, w, 3), dtype=pay_dtype, device=dev) for _ in range(n_buf)] if use_dist else None
+        frames8 = None if use_dist else [torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)]
+        images = [torch.zeros_like(g) for g in gathered] if use_dist and rank == 0 else None
+        my_chunk = [g[rank * c_rows * 32:(rank + 1) * c_rows * 32] for g in gathered] if use_dist else None
+
+        # A dedicated stream: the kernel, the timing events and torch's RCCL op are all ordered
         # on it (torch.cuda.Event only sees the stream it is recorded on).
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize()
         torch.cuda.set_stream(stream)
-        p_ref = C.byref(params)
-        frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
-        # cyclic: the kernel packs this rank's display rows straight into its chunk of the gather buffer
-        frame8_ptrs = [C.c_void_p((ch if cyclic else f8).data_ptr()) for ch, f8 in zip(my_chunk, frames8)]
-        # image-order display frames at the consumer, one per frame in flight
-        displays = [torch.zeros_like(g) for g in gathered] if cyclic and rank == 0 else None
-        display = displays[0] if displays else None
         stream_ptr = C.c_void_p(stream.cuda_stream)
+        p_ref, plain_ref = C.byref(params), C.byref(plain)
+        frame_ptrs = [C.c_void_p(f.data_ptr()) for f in frames]
+        chunk_ptrs = [C.c_void_p(ch.data_ptr()) for ch in my_chunk] if use_dist else None
+        gather_ptrs = [C.c_void_p(g.data_ptr()) for g in gathered] if use_dist else None
+        image_ptrs = [C.c_void_p(d.data_ptr()) for d in images] if images else [None] * n_buf
+        frame8_ptr = C.c_void_p(frames8[0].data_ptr()) if frames8 else None
         has_rows = n_owned > 0
         pending = [None] * n_buf
         counter = [0]
 
-        plain = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)   # the library derives the rank's rows
-        plain.flags = params.flags & 2
-        plain_ref = C.byref(plain)
-        gather_ptrs = [C.c_void_p(g.data_ptr()) for g in gathered]
-        display_ptrs = [C.c_void_p(d.data_ptr()) for d in displays] if displays else [None] * n_buf
+        def check(st):
+            if st != 0:
+                raise pkg.BackendError(st, L.rm_last_error(ctx.ptr).decode())
+
+        def step_single():
+            check(L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[0], frame8_ptr, stream_ptr))
 
         def step_direct():
             """One frame through the library's exchange: render on the slot's own stream, one
-            ncclAllGather and the de-interleave at the consumer behind it on the same stream; returns at once."""
+            ncclAllGather and the de-interleave at the consumer behind it on the same stream;
+            returns at once (a slot is waited for -- bounded -- before it is reused)."""
             b = counter[0] % n_buf
             counter[0] += 1
-            st = L.rm_frame_submit(ctx.ptr, plain_ref, frame_ptrs[b], gather_ptrs[b], display_ptrs[b], b)
-            if st != 0:
-                raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
+            if unit == 1:
+                check(L.rm_frame_submit(ctx.ptr, plain_ref, frame_ptrs[b], gather_ptrs[b], image_ptrs[b], b))
+            else:
+                check(L.rm_frame_submit_f64(ctx.ptr, plain_ref, gather_ptrs[b], image_ptrs[b], b))
 
         def step_torch():
-            """One frame: render this rank's band (f64 rows + their display bytes), then the
-            single collective of the frame (asynchronous: the stream is only made to wait for
-            it when its buffer is about to be rendered into again)."""
-            b = counter[0] % n_buf
+            """One frame: render this rank's rows (f64 rows + their display bytes, the payload
+            packed into this rank's chunk), then the single collective of the frame
+            (asynchronous: the stream is only made to wait for it when its buffer is about to
+            be rendered into again)."""
+            b = counter[0] % n_buf_torch
             counter[0] += 1
             if pending[b] is not None:
                 pending[b].wait()                      # stream-ordered; the host does not block
                 pending[b] = None
-                if displays:
-                    workloads.deinterleave_rows(gathered[b], world, displays[b])
+                if images:
+                    workloads.deinterleave_rows(gathered[b], world, images[b])
             if has_rows:
-                st = L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], frame8_ptrs[b], stream_ptr)
-                if st != 0:
-                    raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
-            if use_dist:
-                pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
+                if unit == 1:
+                    check(L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], chunk_ptrs[b], stream_ptr))
+                else:
+                    check(L.rm_render_device(ctx.ptr, p_ref, chunk_ptrs[b], stream_ptr))
+            pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
 
-        def drain():
+        def drain(direct):
             if direct:
                 for b in range(n_buf):
-                    if L.rm_frame_wait(ctx.ptr, b) != 0:
-                        raise RuntimeError(L.rm_last_error(ctx.ptr).decode())
+                    ctx.frame_wait(b)                   # bounded: raises RM_ERR_TIMEOUT
             for i, wk in enumerate(pending):
                 if wk is not None:
                     wk.wait()
                     pending[i] = None
-                    if displays:
-                        workloads.deinterleave_rows(gathered[i], world, displays[i])
+                    if images:
+                        workloads.deinterleave_rows(gathered[i], world, images[i])
 
-        def fence():
-            drain()
+        def fence(direct=False):
+            drain(direct)
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        if direct:
-            # first frame through both paths: the gathered display bytes must be identical
-            step_torch()
-            fence()
-            want = gathered[0].clone()
-            gathered[0].zero_()
+        def timed(step, direct):
+            """--warmup steps + launches until WARMUP_SECONDS have passed (the same count on
+            every rank), then EXACTLY `steps` steps between fences; max over ranks."""
             counter[0] = 0
-            step_direct()
-            fence()
-            same = torch.tensor([1 if torch.equal(gathered[0], want) else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            counter[0] = 0
-            if int(same.item()) != 1:
-                direct = False
-                ctx.comm_destroy()
-                mode["collective"], mode["note"] = "torch", "library exchange disagreed with the torch path on the check frame"
-        step = step_direct if direct else step_torch
-        for _ in range(warmup):
-            step()
-        # HIP events on the launch stream bracket the timed region (one pair: an event per
-        # launch would put two extra packets between consecutive kernels)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fence()
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for k in range(steps):
-            step()
-        ev1.record(stream)
-        fence()
-        elapsed = time.perf_counter() - t0
+            t_w = time.perf_counter()
+            for _ in range(warmup):
+                step()
+            fence(direct)
+            per = (time.perf_counter() - t_w) / max(warmup, 1)
+            extra = torch.tensor([int(max(0., WARMUP_SECONDS - per * warmup) / max(per, 1e-6)) + 1], dtype=torch.int64, device=dev)
+            if use_dist:
+                dist.broadcast(extra, src=0)
+            for _ in range(min(int(extra.item()), 20000)):
+                step()
+            # HIP events on the launch stream bracket the timed region (one pair: an event per
+            # launch would put two extra packets between consecutive kernels)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fence(direct)
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            for _ in range(steps):
+                step()
+            ev1.record(stream)
+            fence(direct)
+            elapsed = time.perf_counter() - t0
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            # average launch duration of this rank's render kernel over the timed region: at
+            # N = 1 the events bracket exactly the K launches on their stream; with frames in
+            # flight on the slots' own streams there is no per-launch bracket, the per-frame
+            # time of the pipeline is reported instead
+            kernel_ms = ev0.elapsed_time(ev1) / steps if not direct else elapsed / steps * 1e3
+            return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kernel_ms,
+                    "mpx": (w * h) * steps / elapsed / 1e6}
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        paths = {}
+        chosen = "none"
+        if not use_dist:
+            paths["none"] = timed(step_single, False)
+        else:
+            paths["torch"] = dict(timed(step_torch, False), frames_in_flight=n_buf_torch)
+            chosen = "torch"
+            if cfg_id == args.config:
+                note_partial("torch_path", dict(paths["torch"], workload=cfg_id, n_gpus=world))
+            if want_direct and make_comm(ctx):
+                try:
+                    # first frame through both paths: the gathered payload must be identical
+                    want = gathered[0].clone()
+                    want_img = images[0].clone() if images else None
+                    gathered[0].zero_()
+                    counter[0] = 0
+                    step_direct()
+                    fence(True)
+                    same = torch.equal(gathered[0], want) and (want_img is None or torch.equal(images[0], want_img))
+                    flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) != 1:
+                        state["direct_note"] = "library exchange disagreed with the torch path on the check frame"
+                        ctx.comm_destroy()
+                    else:
+                        paths["direct"] = dict(timed(step_direct, True), frames_in_flight=n_buf,
+                                               rccl_sees=dict(zip(("rank", "world", "communicators"), ctx.comm_info())))
+                        t = ctx.frame_timing(0)
+                        paths["direct"]["last_frame_on_stream_ms"] = {"kernel": t.kernel_ms, "gather": t.gather_ms, "total": t.total_ms}
+                        if paths["direct"]["mpx"] >= paths["torch"]["mpx"]:
+                            chosen = "direct"                   # `value` is the faster of the two valid exchanges
+                except pkg.BackendError as e:
+                    if e.status != pkg._lib.RM_ERR_TIMEOUT:
+                        raise
+                    # A peer never joined (or left) the library's collective.  This rank's streams
+                    # are stuck behind it: nothing more can be measured.  Report what the torch
+                    # path measured and leave, non-zero, without another collective.
+                    sys.stderr.write("rank %d: %s\n" % (rank, e))
+                    if rank == 0:
+                        emit(result(cfg, paths, "torch", "direct timed out: %s" % e, kernel_name, n_owned, c_rows, cyclic, None, None, None, []))
+                    sys.stderr.flush()
+                    os._exit(4)
+            elif want_direct:
+                state["direct_note"] = "library communicator could not be created on every rank"
 
-        # average launch duration of this rank's render kernel over the timed region (for
-        # N > 1 the gather's stream time is inside the bracket too, so it is only reported
-        # as the kernel's duration at N = 1)
-        kernel_ms = ev0.elapsed_time(ev1) / steps
-        if direct:
-            # the frames render on the slots' own streams and overlap: there is no per-launch
-            # duration to bracket; report the per-frame time of the pipeline instead
-            kernel_ms = elapsed / steps * 1e3
+        best = paths[chosen]
+        frame, frame8 = frames[0], (frames8[0] if frames8 else None)
+        image = images[0] if images else None
         px_launch = n_owned * 32 * w                                        # pixels one launch writes
 
-        # SURVEY.md 8d (iii): the drop-in call itself, rm_render into pageable host memory
-        # (what Renderer::render hands back), a few frames outside the timed region
-        host = None
-        if world == 1 and rank == 0 and cfg_id == args.config and not args.no_sizes:
+        host = piped = None
+        if extras and world == 1 and rank == 0 and not use_dist:
+            # SURVEY.md 8d (iii): the drop-in call itself, rm_render into host memory (what
+            # Renderer::render hands back), a few frames outside the timed region
             torch.cuda.synchronize()
             host_frame = np.zeros((h, w, 3), dtype=np.float64)
-            p_host = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
-            p_host.flags = params.flags & 2
+            p_host = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+            p_host.flags = fast_flag
             ctx.render(p_host, host_frame)
             ts, tm = [], None
             for _ in range(10):
@@ -344,27 +583,21 @@ def main():
             med = float(np.median(ts))
             host = {"value": w * h / med / 1e6, "unit": "Mpixels/s", "ms_per_frame": med * 1e3,
                     "kernel_ms": tm.kernel_ms, "d2h_ms": tm.d2h_ms,
-                    "what": "rm_render(): kernel + device-to-host copy of the f64 frame into pageable memory, median of 10"}
-        # the same frames with four in flight, each on a stream of its own (rm_frame_submit with no
-        # communicator): what a renderer gets that need not wait for frame k before starting
-        # k+1 -- the ramp and drain of one frame fill with the others (four: HIP maps streams onto
-        # four hardware queues, and two slots may land on one).  Not the metric: a step
-        # of the metric is one frame at a time, like the reference's render().
-        piped = None
-        if world == 1 and rank == 0 and not use_dist and cfg_id == args.config and not args.no_sizes:
-            torch.cuda.synchronize()
+                    "what": "rm_render(): kernel + device-to-host copy of the f64 frame into the caller's pageable memory, median of 10"}
+            # the same frames with four in flight, each on a stream of its own (rm_frame_submit with no
+            # communicator): what a renderer gets that need not wait for frame k before starting
+            # k+1 -- the ramp and drain of one frame fill with the others.  Not the metric: a step
+            # of the metric is one frame at a time, like the reference's render().
             n_slots = 4
-            pf = [torch.zeros((pad_h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_slots)]
+            pf = [torch.zeros((h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_slots)]
             pg = [torch.zeros((n_rows * 32, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)]
-            p_plain = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
-            p_plain.flags = params.flags & 2
             n_frames = max(steps, 30)
             for k in range(n_slots * 4 + n_frames):
                 if k == n_slots * 4:
                     for b in range(n_slots):
                         ctx.frame_wait(b)
                     t1 = time.perf_counter()
-                ctx.frame_submit(p_plain, pf[k % n_slots].data_ptr(), pg[k % n_slots].data_ptr(), None, k % n_slots)
+                ctx.frame_submit(plain, pf[k % n_slots].data_ptr(), pg[k % n_slots].data_ptr(), None, k % n_slots)
             for b in range(n_slots):
                 ctx.frame_wait(b)
             dt = time.perf_counter() - t1
@@ -375,108 +608,146 @@ def main():
                 piped["identical_to_single_stream_frame"] = bool(torch.equal(pf[0][:n_rows * 32], frame[:n_rows * 32])
                                                                  and torch.equal(pg[0], frame8[:n_rows * 32]))
             del pf, pg
-        res = dict(cfg=cfg, w=w, h=h, depth=depth, n_rows=n_rows, c_rows=c_rows, cyclic=cyclic, host=host, piped=piped,
-                   collective=("direct" if direct else mode["collective"]), frames_in_flight=n_buf,
-                   elapsed=elapsed, kernel_ms=kernel_ms, px_launch=px_launch,
-                   mpx=(w * h) * steps / elapsed / 1e6,
-                   frame=frame, frame8=frame8, display=display)
+        checks = None
+        if args.check and rank == 0:
+            O = G.load_oracle()
+            ref = O.render(workloads.oracle_scene(O, cfg["scene"]), w, h, max_depth=depth)[:n_rows * 32]
+            checks = {}
+            f64 = frame[:n_rows * 32] if not use_dist else (image[:n_rows * 32] if unit == 8 else None)
+            if f64 is not None:
+                checks["max_abs_delta_vs_oracle"] = float(np.abs(f64.cpu().numpy() - ref).max())
+            u8 = frame8[:n_rows * 32] if not use_dist else (image[:n_rows * 32] if unit == 1 else None)
+            if u8 is not None:
+                checks["display_bytes_differing_from_oracle"] = int((u8.cpu().numpy().reshape(-1) != O.to_vec(ref.copy())).sum())
+        res = dict(cfg=cfg, paths=paths, chosen=chosen, kernel_name=kernel_name, n_owned=n_owned, c_rows=c_rows, cyclic=cyclic,
+                   host=host, piped=piped, checks=checks, px_launch=px_launch, best=best)
         ctx.close()
+        torch.cuda.empty_cache()
         return res
 
-    r = run_workload(args.config, args.steps, args.warmup)
-    cfg, w, h, depth, n_rows, c_rows, cyclic = (r[k] for k in ("cfg", "w", "h", "depth", "n_rows", "c_rows", "cyclic"))
-    elapsed, kernel_ms, px_launch = r["elapsed"], r["kernel_ms"], r["px_launch"]
-    frame, frame8, display = r["frame"], r["frame8"], r["display"]
-    # north star: "Mpixels/sec on synthetic 1080p/4K/8K frames": the larger frames of the
-    # same scene, a short run each (same sharding and collective), reported beside the metric
-    other = []
-    if args.config == "C2" and not args.no_sizes:
-        for cid in ("C2_4K", "C4"):
-            o = run_workload(cid, max(5, min(args.steps, 20)), 3)
-            ach = o["px_launch"] * BYTES_PER_PIXEL / (o["kernel_ms"] * 1e-3) / 1e9
-            other.append({"workload": "%s: %s scene %dx%d, depth cap %d" % (cid, o["cfg"]["scene"], o["w"], o["h"], o["depth"]),
-                          "value": o["mpx"], "unit": "Mpixels/s", "ms_per_step": o["elapsed"] / max(5, min(args.steps, 20)) * 1e3,
-                          "roofline_frac": (ach / HBM_PEAK_GBPS) if world == 1 else None})
-            o.clear()
-            torch.cuda.empty_cache()
-
-    if rank == 0:
-        mpx = r["mpx"]
+    def result(cfg, paths, chosen, note, kernel_name, n_owned, c_rows, cyclic, host, piped, checks, other):
+        """The JSON line."""
+        w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
+        best = paths[chosen]
+        px_launch = n_owned * 32 * w
+        kernel_ms = best["kernel_ms"]
         achieved = px_launch * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
-        traffic, valu = None, None
+        traffic, valu, pmc_note = None, None, "no profiles/pmc_latest.json for this config"
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and world == 1:
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("config") == args.config and pmc.get("n_gpus", 1) == world:
+                if pmc.get("config") != args.config:
+                    pmc_note = "profiles/pmc_latest.json is of config %s" % pmc.get("config")
+                elif pmc.get("csrc_sha16") != csrc_hash() or pmc.get("kernel") != kernel_name:
+                    pmc_note = ("profiles/pmc_latest.json was collected on another build of the kernel sources "
+                                "(csrc hash / kernel name differ): traffic not reported")
+                else:
                     traffic = pmc.get("hbm_bytes_per_launch")
-                    valu = {k: pmc.get(k) for k in ("valu_busy_frac", "valu_lanes_active_frac", "valu_wave_instructions")}
+                    valu = {k: pmc.get(k) for k in ("valu_busy_frac", "valu_lanes_active_frac", "valu_wave_instructions",
+                                                    "salu_wave_instructions", "wait_any_frac", "wait_inst_any_frac")}
                     if valu["valu_wave_instructions"]:
-                        # the bound that does apply: one 64-lane VALU instruction per SIMD per 4 cycles
+                        # the bound that does apply: one 64-lane FP64 VALU instruction per SIMD per 4 cycles
                         # (1024 SIMDs, 2.4 GHz peak clock) against this run's kernel time
                         valu["valu_issue_frac_of_peak"] = (valu["valu_wave_instructions"] * 4.0
                                                            / (1024 * 2.4e9 * kernel_ms * 1e-3))
-            except Exception:
-                traffic = None
+                    pmc_note = ("traffic and fp64_valu are rocprofv3 PMC figures of this command on this build "
+                                "(profiles/pmc_latest.json: csrc hash and kernel name match), not measured in this run")
+            except Exception as e:                      # noqa: BLE001
+                pmc_note = "profiles/pmc_latest.json unreadable: %s" % e
+        coll = {"none": "none (one GPU)",
+                "direct": "rm_frame_submit%s: ncclAllGather from the C library" % ("_f64" if args.payload == "f64" else ""),
+                "torch": "torch.distributed.all_gather_into_tensor (%s)" % ("RCCL" if backend == "nccl" else backend)}[chosen]
+        note = note or state["direct_note"]
         out = {
             "metric": "Mpixels/sec at 1920x1080, max-bounce=5" if args.config == "C2"
                       else "Mpixels/sec (%s)" % args.config,
-            "value": mpx, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": best["mpx"], "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": best["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s scene %dx%d, depth cap %d, fov 1.5, device-resident f64 RGB frame"
                                    % (args.config, cfg["scene"], w, h, depth),
-                       "sharding": "%s of %d patch rows (32 px) per rank, %d rank(s)%s"
-                                   % ("cyclic rows (r, r+N, ...)" if cyclic else "contiguous bands", c_rows, world, (", one in-place RCCL all-gather of the %s rows per frame; "
-                                                      "f64 rows stay in each rank's HBM" % args.payload)
-                                      if world > 1 else ""),
-                       "collective": {"none": "none (one GPU)",
-                                      "direct": "rm_frame_submit: ncclAllGather from the C library, %d frames in flight, "
-                                                "each rendering on a stream of its own" % r["frames_in_flight"],
-                                      "torch": "torch.distributed.all_gather_into_tensor (%s), %d frames in flight"
-                                               % ("RCCL" if backend == "nccl" else backend, r["frames_in_flight"])}[r["collective"]]
-                                     + (" [%s]" % mode["note"] if mode["note"] else ""),
+                       "sharding": ("cyclic patch rows (rank r: rows r, r+N, ...), %d of 32 px per rank, %d rank(s), one in-place "
+                                    "RCCL all-gather of the %s rows per frame%s"
+                                    % (c_rows, world, args.payload, "" if args.payload == "f64" else "; f64 rows stay in each rank's HBM"))
+                                   if cyclic else "one GPU renders all %d patch rows" % c_rows,
+                       "collective": coll + (" [%s]" % note if note else ""),
+                       "frames_in_flight": best.get("frames_in_flight", 1),
+                       "warmup_policy": "--warmup steps, then launches until %.1f s have passed" % WARMUP_SECONDS,
                        "outputs": "f64 RGB frame [H][W][3] + u8 display frame (to_vec) per launch",
-                       "numerics": "fast" if args.fast_fp else "strict (the reference's operations, one rounding each)",
-                       "build": L.rm_build_info().decode()},
+                       "numerics": ("fast (FMA contraction, Newton rsqrt; exact-incidence pixels may differ)" if args.fast_fp else
+                                    "strict: every hit / miss / shadow / side decision computed with the reference's operations, "
+                                    "one rounding each, in its order; colour sums after the shadow test use FMAs, the viewer "
+                                    "direction is the ray's, integer specular exponents by repeated multiplication "
+                                    "(measured max |delta| 4e-14, asserted < 1e-9)"),
+                       "build": L.rm_build_info().decode(), "csrc_sha16": csrc_hash()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rmdev_fast::rm_render_static" if args.fast_fp else "rmdev_strict::rm_render_static", "kernel_ms": kernel_ms,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "bytes_per_launch": px_launch * BYTES_PER_PIXEL,
                          "fp64_valu": valu,
                          "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); achieved = 24 B x pixels "
-                                 "written / kernel time; traffic and fp64_valu are PMC figures of the same command "
-                                 "(profiles/pmc_latest.json), not measured in this run"},
+                                 "written / kernel time (HIP events on the launch stream); " + pmc_note},
         }
-        if args.check:
-            O = G.load_oracle()
-            ref = O.render(workloads.oracle_scene(O, cfg["scene"]), w, h, max_depth=depth)
-            # what rank 0 holds after the last frame: the whole f64 frame (N = 1, or f64
-            # payload), and / or the whole display frame (N = 1, or u8 payload)
-            if world == 1 or args.payload == "f64":
-                got = frame[:n_rows * 32].cpu().numpy()
-                out["max_abs_delta_vs_oracle"] = float(np.abs(got - ref[:n_rows * 32]).max())
-            if world == 1 or args.payload == "u8":
-                u8 = (display if display is not None else frame8)[:n_rows * 32].cpu().numpy().reshape(-1)
-                out["display_bytes_differing_from_oracle"] = int((u8 != O.to_vec(ref[:n_rows * 32].copy())).sum())
-        if world == 1 and not args.no_cpu_baseline:
-            O = G.load_oracle()
-            out["cpu_baseline"] = cpu_baseline(O, workloads, cfg)
-            out["speedup_vs_cpu_baseline"] = mpx / out["cpu_baseline"]["value"]
-        if r["host"]:
-            out["end_to_end_host"] = r["host"]
-        if r["piped"]:
-            out["four_frames_in_flight"] = r["piped"]
+        if world > 1 or args.force_dist:
+            out["exchange_paths"] = paths
+        if checks:
+            out.update(checks)
+        if host:
+            out["end_to_end_host"] = host
+        if piped:
+            out["four_frames_in_flight"] = piped
         if other:
             out["other_frames"] = other
+        return out
+
+    def emit(out):
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+
+    r = run_workload(args.config, args.steps, args.warmup, extras=not args.no_sizes)
+    # north star: "Mpixels/sec on synthetic 1080p/4K/8K frames", and the other GPU configs of
+    # BASELINE.json (cornell C3, synthetic C5): a short run each (same sharding and collective),
+    # reported beside the metric with their own kernel and roofline fraction
+    other = []
+    if args.config == "C2" and not args.no_sizes:
+        for cid in ("C2_4K", "C4", "C3", "C5"):
+            k = max(5, min(args.steps, 20 if cid != "C3" else 100))
+            o = run_workload(cid, k, 3)
+            ach = o["px_launch"] * BYTES_PER_PIXEL / (o["best"]["kernel_ms"] * 1e-3) / 1e9
+            other.append({"workload": "%s: %s scene %dx%d, depth cap %d" % (cid, o["cfg"]["scene"], o["cfg"]["width"], o["cfg"]["height"], o["cfg"]["max_depth"]),
+                          "value": o["best"]["mpx"], "unit": "Mpixels/s", "steps": k, "ms_per_step": o["best"]["ms_per_step"],
+                          "kernel": o["kernel_name"], "kernel_ms": o["best"]["kernel_ms"] if world == 1 else None,
+                          "collective": o["chosen"],
+                          "roofline_frac": (ach / HBM_PEAK_GBPS) if world == 1 else None})
+            o.clear()
+
+    if rank == 0:
+        out = result(r["cfg"], r["paths"], r["chosen"], None, r["kernel_name"], r["n_owned"], r["c_rows"], r["cyclic"],
+                     r["host"], r["piped"], r["checks"], other)
+        if world == 1 and not args.no_cpu_baseline:
+            O = G.load_oracle()
+            out["cpu_baseline"] = cpu_baseline(O, workloads, r["cfg"])
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        emit(out)
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)                       # before anything touches a GPU
+    if args.dry_run:
+        return dry_main(args)
+    return rank_main(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

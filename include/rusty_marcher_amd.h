@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 1u
+#define RM_ABI_VERSION 2u
 
 typedef enum rm_status {
     RM_OK = 0,
@@ -44,7 +44,10 @@ typedef enum rm_status {
                                 panics "WOOPS", obj.rs:64) */
     RM_ERR_PARSE = 8,
     RM_ERR_DEPTH = 9,        /* max_depth outside [0, RM_MAX_DEPTH] */
-    RM_ERR_COMM = 10         /* RCCL unavailable or a collective failed (rm_comm_*, rm_frame_*) */
+    RM_ERR_COMM = 10,        /* RCCL unavailable or a collective failed (rm_comm_*, rm_frame_*) */
+    RM_ERR_TIMEOUT = 11      /* rm_frame_wait*: the slot's frame did not complete in time (a peer is
+                                missing or stuck in the collective); the context is not usable for
+                                further frames -- report and exit */
 } rm_status;
 
 /* Recursion cap accepted by rm_render.  The reference hard-codes 3
@@ -144,6 +147,10 @@ typedef struct rm_params {
  * k-th owned patch row occupies byte rows [32k, 32k + 32) of a [n_owned*32][frame_width][3]
  * buffer -- so that a rank's display bytes are one contiguous chunk for a gather. */
 #define RM_FLAG_U8_COMPACT 4u
+/* rm_render_device / rm_render_device_u8: device_rgb holds just the OWNED patch rows, packed
+ * the same way ([n_owned*32][frame_width][3] doubles): a rank's f64 rows as one contiguous
+ * chunk (what rm_frame_submit_f64 gathers). */
+#define RM_FLAG_F64_COMPACT 8u
 
 typedef struct rm_timing {
     double kernel_ms;   /* HIP-event time of the render kernel on its stream */
@@ -268,6 +275,8 @@ rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t frame_width, ui
 rm_status rm_buffer_alloc(rm_ctx *ctx, size_t bytes, void **device_ptr);
 void rm_buffer_free(rm_ctx *ctx, void *device_ptr);
 rm_status rm_buffer_read(rm_ctx *ctx, const void *device_ptr, void *host_dst, size_t bytes);
+/* Synchronous host -> device copy (e.g. a FrameBuffer's contents for rm_postprocess). */
+rm_status rm_buffer_write(rm_ctx *ctx, void *device_ptr, const void *host_src, size_t bytes);
 /* Page-locked host memory: the destination rm_frame_submit can copy a finished display
  * frame into asynchronously (a pageable destination would make the copy synchronous). */
 rm_status rm_host_alloc(rm_ctx *ctx, size_t bytes, void **host_ptr);
@@ -279,9 +288,11 @@ void rm_host_free(rm_ctx *ctx, void *host_ptr);
  * every rank gets its share of cheap sky and expensive ground rows), each rank's f64 rows
  * stay in its own `device_rgb` (a distributed FrameBuffer), and ONE in-place RCCL
  * all-gather per frame completes the display frame (`to_vec` bytes, framebuffer.rs:40-55)
- * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream and a
- * communicator of its own (render, gather, de-interleave in order on the stream); every rank
- * must submit the same sequence of (frame, slot) pairs.
+ * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream of its
+ * own (render, gather, de-interleave in order on the stream); every rank must submit the
+ * same sequence of (frame, slot) pairs.  All slots share ONE communicator unless
+ * RM_SLOT_COMMS=1 is exported on EVERY rank (then each slot gets one split off the first;
+ * the ranks agree by an all-reduce whether every split succeeded, else all keep the one).
  *
  * Bootstrap: rank 0 calls rm_comm_unique_id and hands the RM_COMM_ID_BYTES to the other
  * ranks by any channel (a file, a socket, torch.distributed's store); every rank then
@@ -314,14 +325,43 @@ rm_status rm_frame_submit(rm_ctx *ctx, const rm_params *params, void *device_rgb
  * of fb.to_vec() are in host memory (main.rs:337-346 hands them to the pixbuf). */
 rm_status rm_frame_submit_to_host(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_gather8,
                                   void *device_display8, void *host_display8, uint32_t slot);
-/* Blocks the host until the slot's last frame is complete on this rank. */
+/* Blocks the host until the slot's last frame is complete on this rank.  With a
+ * communicator the wait is bounded: RM_ERR_TIMEOUT after RM_FRAME_TIMEOUT_MS (environment,
+ * default 60000; 0 = wait for ever) -- a peer that never joins the collective must not hang
+ * the host. */
 rm_status rm_frame_wait(rm_ctx *ctx, uint32_t slot);
+/* The same with an explicit bound in milliseconds (0 = wait for ever). */
+rm_status rm_frame_wait_for(rm_ctx *ctx, uint32_t slot, uint32_t timeout_ms);
+
+/*
+ * The f64 frame itself (framebuffer.rs:6-22: the reference's render target is f64) to the
+ * consumer: this rank's rows are rendered packed (RM_FLAG_F64_COMPACT) straight into its
+ * chunk of device_gather64 (world * 8 * chunk_bytes of rm_exchange_layout), ONE in-place
+ * all-gather completes the buffer on every rank, and -- where device_frame64 is not NULL --
+ * the [32*n_patch_rows][W][3] f64 frame is written in image order, bit-identical to the
+ * single-GPU frame.  8x the bytes of the display path: at 1080p ~6 MB per peer per frame.
+ * Frames in flight (slots) overlap one frame's gather with the next frame's render.
+ */
+rm_status rm_frame_submit_f64(rm_ctx *ctx, const rm_params *params, void *device_gather64, void *device_frame64,
+                              uint32_t slot);
+
+/* Device times of the slot's last completed frame (call after rm_frame_wait): render kernel,
+ * collective, and everything of the frame on its stream. */
+typedef struct rm_frame_times { double kernel_ms, gather_ms, total_ms; } rm_frame_times;
+rm_status rm_frame_timing(rm_ctx *ctx, uint32_t slot, rm_frame_times *out);
+
+/* What the communicator itself reports (ncclCommUserRank / ncclCommCount) and how many
+ * communicators the slots use; world 1 / rank 0 / 0 communicators without one. */
+rm_status rm_comm_info(rm_ctx *ctx, int *rank, int *world, int *n_communicators);
 
 
 /* Library / device introspection for harnesses. */
 uint32_t    rm_abi_version(void);
 const char *rm_build_info(void);
 rm_status   rm_device_info(rm_ctx *ctx, char *name_buf, size_t buflen, int *n_cus, size_t *lds_bytes);
+/* Name of the kernel a render of the uploaded scene with `params` launches, as a kernel trace
+ * (rocprofv3) prints it: ties a measured launch to its profile. */
+rm_status   rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t buflen);
 
 #ifdef __cplusplus
 }

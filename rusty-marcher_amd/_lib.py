@@ -9,7 +9,8 @@ LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(_HERE, "lib", "librusty
 RM_OK = 0
 RM_ERR_INVALID_ARG, RM_ERR_DIMENSIONS, RM_ERR_NO_DEVICE, RM_ERR_HIP = 1, 2, 3, 4
 RM_ERR_NO_SCENE, RM_ERR_SCENE_LIMIT, RM_ERR_IO, RM_ERR_PARSE, RM_ERR_DEPTH = 5, 6, 7, 8, 9
-RM_ERR_COMM = 10
+RM_ERR_COMM, RM_ERR_TIMEOUT = 10, 11
+RM_FLAG_FAST_FP, RM_FLAG_U8_COMPACT, RM_FLAG_F64_COMPACT = 2, 4, 8
 RM_MAX_DEPTH = 32
 RM_COMM_ID_BYTES, RM_MAX_FRAME_SLOTS = 128, 4
 RM_PATCH_SIZE = 32
@@ -17,7 +18,7 @@ RM_SHAPE_SPHERE, RM_SHAPE_POLYGON, RM_SHAPE_MESH = 0, 1, 2
 
 STATUS_NAMES = {0: "RM_OK", 1: "RM_ERR_INVALID_ARG", 2: "RM_ERR_DIMENSIONS", 3: "RM_ERR_NO_DEVICE",
                 4: "RM_ERR_HIP", 5: "RM_ERR_NO_SCENE", 6: "RM_ERR_SCENE_LIMIT", 7: "RM_ERR_IO",
-                8: "RM_ERR_PARSE", 9: "RM_ERR_DEPTH", 10: "RM_ERR_COMM"}
+                8: "RM_ERR_PARSE", 9: "RM_ERR_DEPTH", 10: "RM_ERR_COMM", 11: "RM_ERR_TIMEOUT"}
 
 
 class rm_vec3(C.Structure):
@@ -76,6 +77,10 @@ class rm_timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class rm_frame_times(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 _P = C.POINTER
 _VP = C.c_void_p
 
@@ -110,6 +115,7 @@ SIGNATURES = {
     "rm_buffer_alloc": (C.c_int, [_VP, C.c_size_t, _P(_VP)]),
     "rm_buffer_free": (None, [_VP, _VP]),
     "rm_buffer_read": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "rm_buffer_write": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "rm_host_alloc": (C.c_int, [_VP, C.c_size_t, _P(_VP)]),
     "rm_host_free": (None, [_VP, _VP]),
     "rm_frame_submit_to_host": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP, _VP, C.c_uint32]),
@@ -119,9 +125,14 @@ SIGNATURES = {
     "rm_exchange_layout": (C.c_int, [_P(rm_params), C.c_int, _P(C.c_uint32), _P(C.c_size_t)]),
     "rm_frame_submit": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP, C.c_uint32]),
     "rm_frame_wait": (C.c_int, [_VP, C.c_uint32]),
+    "rm_frame_wait_for": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "rm_frame_submit_f64": (C.c_int, [_VP, _P(rm_params), _VP, _VP, C.c_uint32]),
+    "rm_frame_timing": (C.c_int, [_VP, C.c_uint32, _P(rm_frame_times)]),
+    "rm_comm_info": (C.c_int, [_VP, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "rm_abi_version": (C.c_uint32, []),
     "rm_build_info": (C.c_char_p, []),
     "rm_device_info": (C.c_int, [_VP, C.c_char_p, C.c_size_t, _P(C.c_int), _P(C.c_size_t)]),
+    "rm_kernel_name": (C.c_int, [_VP, _P(rm_params), C.c_char_p, C.c_size_t]),
 }
 
 _lib = None

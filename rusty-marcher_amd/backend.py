@@ -74,8 +74,49 @@ class Context:
         _lib.check(self.L.rm_frame_submit(self.ptr, C.byref(params), C.c_void_p(device_ptr), C.c_void_p(gather_ptr),
                                           C.c_void_p(display_ptr) if display_ptr else None, slot), self.ptr)
 
-    def frame_wait(self, slot=0):
-        _lib.check(self.L.rm_frame_wait(self.ptr, slot), self.ptr)
+    def frame_submit_f64(self, params, gather_ptr, frame_ptr=None, slot=0):
+        """The f64 rows themselves: rendered packed into this rank's chunk of gather_ptr,
+        all-gathered in place, written in image order to frame_ptr where given."""
+        _lib.check(self.L.rm_frame_submit_f64(self.ptr, C.byref(params), C.c_void_p(gather_ptr),
+                                              C.c_void_p(frame_ptr) if frame_ptr else None, slot), self.ptr)
+
+    def frame_wait(self, slot=0, timeout_ms=None):
+        """Raises BackendError(RM_ERR_TIMEOUT) instead of hanging when a peer never joins."""
+        if timeout_ms is None:
+            _lib.check(self.L.rm_frame_wait(self.ptr, slot), self.ptr)
+        else:
+            _lib.check(self.L.rm_frame_wait_for(self.ptr, slot, int(timeout_ms)), self.ptr)
+
+    def frame_timing(self, slot=0):
+        t = _lib.rm_frame_times()
+        _lib.check(self.L.rm_frame_timing(self.ptr, slot, C.byref(t)), self.ptr)
+        return t
+
+    def comm_info(self):
+        """(rank, world, communicators in use) as the RCCL communicator itself reports them."""
+        r, w, n = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self.L.rm_comm_info(self.ptr, C.byref(r), C.byref(w), C.byref(n)), self.ptr)
+        return r.value, w.value, n.value
+
+    # ---- device buffers without torch (rm_buffer_*) ----
+    def buffer_alloc(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(self.L.rm_buffer_alloc(self.ptr, int(nbytes), C.byref(p)), self.ptr)
+        return p
+
+    def buffer_free(self, dptr):
+        self.L.rm_buffer_free(self.ptr, dptr)
+
+    def buffer_write(self, dptr, host_array):
+        _lib.check(self.L.rm_buffer_write(self.ptr, dptr, host_array.ctypes.data_as(C.c_void_p), host_array.nbytes), self.ptr)
+
+    def buffer_read(self, dptr, host_array):
+        _lib.check(self.L.rm_buffer_read(self.ptr, dptr, host_array.ctypes.data_as(C.c_void_p), host_array.nbytes), self.ptr)
+
+    def kernel_name(self, params):
+        buf = C.create_string_buffer(256)
+        _lib.check(self.L.rm_kernel_name(self.ptr, C.byref(params), buf, 256), self.ptr)
+        return buf.value.decode()
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -36,7 +36,16 @@ struct rm_aabb {
 struct rm_bvh {
     std::vector<double> nodes;        // RM_BVH_NODE_WORDS per node, node 0 is the root
     std::vector<uint32_t> order;      // order[k] = index (into the input boxes) of the k-th primitive after reordering
+    uint32_t depth = 0;               // inner nodes on the longest root-to-leaf path = entries the kernel's walk can park
 };
+
+// The kernel's walk parks one sibling per level on a 64-entry stack per wave.  The surface-area
+// split alone has no depth bound (spheres whose radii double along a line give one level per
+// sphere), so below RM_BVH_SAH_DEPTH levels the builder splits at the median: from there the
+// depth is at most log2(count), and the whole tree stays under RM_BVH_MAX_DEPTH for any
+// primitive count a 32-bit index can address.  rm_scene_upload checks `depth` all the same.
+#define RM_BVH_SAH_DEPTH 24u
+#define RM_BVH_MAX_DEPTH 60u
 
 namespace rm_bvh_detail {
 
@@ -53,8 +62,9 @@ struct Builder {
     uint32_t leaf_size;
     rm_bvh &out;
 
-    // Builds the subtree over order[first, first+count); returns its ref and box.
-    uint64_t build(uint32_t first, uint32_t count, rm_aabb &box) {
+    // Builds the subtree over order[first, first+count) whose root sits `depth` levels below
+    // the hierarchy's root; returns its ref and box.
+    uint64_t build(uint32_t first, uint32_t count, rm_aabb &box, uint32_t depth) {
         box.reset();
         for (uint32_t k = 0; k < count; k++) box.grow(boxes[out.order[first + k]]);
         if (count <= leaf_size) return ((uint64_t)count << 32) | first;           // leaf
@@ -78,16 +88,19 @@ struct Builder {
             for (uint32_t k = 1; k < count; k++) {
                 acc.grow(boxes[tmp[k - 1]]);
                 const double cost = area(acc) * k + right_area[k] * (count - k);
-                if (cost < best_cost) { best_cost = cost; half = k; axis = a; best_order = tmp; }
+                const bool balanced = depth < RM_BVH_SAH_DEPTH || k == count / 2;   // deep down: median only
+                if (balanced && cost < best_cost) { best_cost = cost; half = k; axis = a; best_order = tmp; }
             }
         }
         (void)axis;
+        if (depth >= RM_BVH_SAH_DEPTH && best_order.empty()) half = count / 2;   // (costs were not finite)
+        out.depth = std::max(out.depth, depth + 1u);
         if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), out.order.begin() + first);
         const uint32_t me = (uint32_t)(out.nodes.size() / RM_BVH_NODE_WORDS);
         out.nodes.resize(out.nodes.size() + RM_BVH_NODE_WORDS, 0.);
         rm_aabb lb, rb;
-        const uint64_t lref = build(first, half, lb);
-        const uint64_t rref = build(first + half, count - half, rb);
+        const uint64_t lref = build(first, half, lb, depth + 1u);
+        const uint64_t rref = build(first + half, count - half, rb, depth + 1u);
         inflate(lb);
         inflate(rb);
         double *n = &out.nodes[(size_t)me * RM_BVH_NODE_WORDS];
@@ -108,7 +121,7 @@ inline rm_bvh rm_build_bvh(const std::vector<rm_aabb> &boxes, uint32_t leaf_size
     for (uint32_t i = 0; i < boxes.size(); i++) out.order[i] = i;
     rm_bvh_detail::Builder b{boxes, leaf_size, out};
     rm_aabb root;
-    b.build(0, (uint32_t)boxes.size(), root);
+    b.build(0, (uint32_t)boxes.size(), root, 0);
     return out;
 }
 

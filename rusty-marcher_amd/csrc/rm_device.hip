@@ -105,6 +105,7 @@ enum { TILE_ORDER_NATURAL = 0, TILE_ORDER_REVERSE = 1, TILE_ORDER_HASH = 2 };
 // A frame in flight (rm_frame_submit): its own render stream, so that consecutive frames overlap.
 struct rm_frame_slot {
     hipStream_t render = nullptr;
+    hipEvent_t begun = nullptr, rendered = nullptr, gathered = nullptr;   // stamps of the frame on the slot's stream
     hipEvent_t exchanged = nullptr;   // recorded after the last operation of the slot's frame
     bool used = false;
 };
@@ -142,7 +143,9 @@ struct rm_ctx {
 
     // multi-GPU frames (rm_exchange.inc)
     void *comm = nullptr;             // ncclComm_t
-    void *slot_comm[RM_MAX_FRAME_SLOTS] = {};   // per frame slot: communicators split off `comm` (or `comm` itself)
+    void *slot_comm[RM_MAX_FRAME_SLOTS] = {};   // per frame slot: `comm` itself, or (RM_SLOT_COMMS=1) one split off it
+    int n_comms = 0;                  // distinct communicators in use
+    bool comm_failed = false;         // a frame wait timed out: the communicator is abandoned, not destroyed
     bool comm_local = false;          // rank/world set without a transport (rm_comm_init with id == NULL)
     int rank = 0, world = 1;
     rm_frame_slot slots[RM_MAX_FRAME_SLOTS];
@@ -276,8 +279,10 @@ void rm_destroy(rm_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rm_comm_destroy(ctx);
     for (rm_frame_slot &s : ctx->slots) {
-        if (s.render) { (void)hipStreamSynchronize(s.render); (void)hipStreamDestroy(s.render); }
-        if (s.exchanged) (void)hipEventDestroy(s.exchanged);
+        // after a timed-out collective the slot's stream never drains: leave it to process exit
+        if (s.render && !ctx->comm_failed) { (void)hipStreamSynchronize(s.render); (void)hipStreamDestroy(s.render); }
+        for (hipEvent_t e : {s.begun, s.rendered, s.gathered, s.exchanged})
+            if (e) (void)hipEventDestroy(e);
     }
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -404,6 +409,11 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.off_materials = take(n_prims * RM_MATERIAL_WORDS);
     H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
     H.off_keys = take((n_prims + 1u) / 2u);
+    // The wave's hierarchy stack holds 64 entries, one parked sibling per level: the builder
+    // keeps every tree under RM_BVH_MAX_DEPTH levels (rm_bvh.hpp); a tree that is deeper all
+    // the same is not walked (its primitives keep their leaf order and are walked flat).
+    if (bvh_s.depth > RM_BVH_MAX_DEPTH) bvh_s.nodes.clear();
+    if (bvh_t.depth > RM_BVH_MAX_DEPTH) bvh_t.nodes.clear();
     H.off_bvh_spheres = bvh_s.nodes.empty() ? 0u : take((uint32_t)bvh_s.nodes.size());
     H.off_bvh_triangles = bvh_t.nodes.empty() ? 0u : take((uint32_t)bvh_t.nodes.size());
     take(64u);                                               // batch loads may read past the last record
@@ -519,6 +529,38 @@ static rm_status check_params(rm_ctx *ctx, const rm_params *p, rm_band *band) {
     return RM_OK;
 }
 
+// Which kernel instantiation a render with these params launches, and how.
+struct rm_kernel_choice {
+    const void *fn = nullptr;
+    rm_launch_mode mode;
+    size_t lds_bytes = 0;
+    int stack = 0, pow_mode = 0;
+    bool fast = false, staged = false, bvh = false;
+};
+
+static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice *k) {
+    // launch geometry: one tile per wave; small scenes get one wave per workgroup,
+    // larger ones share the LDS copy of the scene between four waves
+    rm_launch_mode m = ctx->mode;
+    const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
+    k->bvh = ctx->H.off_bvh_spheres != 0 || ctx->H.off_bvh_triangles != 0;
+    k->staged = scene_bytes <= RM_LDS_SCENE_LIMIT_BYTES && !ctx->force_unstaged && !k->bvh;
+    if (m.waves == 0 || !k->staged) { m.waves = k->staged ? 1 : 4; m.per_wave = 1; }
+    k->mode = m;
+    k->lds_bytes = ((k->staged ? (size_t)ctx->H.total_words : 0u) + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
+
+    // The walk descends into the refracted child directly and parks the reflected one:
+    // at most one pending sibling per level below the cap, i.e. max_depth - 1 entries.
+    k->stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
+    k->pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
+    k->fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
+    if (!k->staged) k->fn = k->bvh ? pick_unstaged<true>(k->stack, k->pow_mode, k->fast) : pick_unstaged<false>(k->stack, k->pow_mode, k->fast);
+    else if (m.waves == 1 && m.per_wave == 1) k->fn = pick_static<1, 1>(k->stack, k->pow_mode, k->fast);
+    else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE (this build keeps s1x1 only; "
+                                                  "the other geometries are in profiles/r01_ab_launch_modes.txt)");
+    return RM_OK;
+}
+
 static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &band, double *d_frame,
                                uint8_t *d_frame8, hipStream_t stream) {
     const uint32_t n_rows = band.count();
@@ -529,7 +571,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         // one fill per run of consecutive owned rows (a single run unless the band is strided)
         const uint32_t run = band.stride == 1 ? n_rows : 1u;
         for (uint32_t k = 0; k < n_rows; k += run) {
-            const size_t first_px = (size_t)(row_begin + k * band.stride) * 32u * p->frame_width;
+            const size_t first_px = (size_t)((p->flags & RM_FLAG_F64_COMPACT) ? k : row_begin + k * band.stride) * 32u * p->frame_width;
             const size_t n_px = (size_t)run * 32u * p->frame_width;
             hipLaunchKernelGGL(rm_fill_band_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, d_frame,
                                first_px, n_px, p->background.x, p->background.y, p->background.z);
@@ -546,6 +588,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     a.patch_row_begin = row_begin;
     a.patch_row_stride = band.stride;
     a.u8_compact = (p->flags & RM_FLAG_U8_COMPACT) ? 1u : 0u;
+    a.f64_compact = (p->flags & RM_FLAG_F64_COMPACT) ? 1u : 0u;
     a.max_depth = p->max_depth;
     a.n_width = n_width;
     a.n_tiles = n_rows * n_width * 16u;
@@ -562,27 +605,13 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         a.order_mul = mul % a.n_tiles;
     }
 
-    // launch geometry: one tile per wave; small scenes get one wave per workgroup,
-    // larger ones share the LDS copy of the scene between four waves
-    rm_launch_mode m = ctx->mode;
-    const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
-    const bool bvh = ctx->H.off_bvh_spheres != 0 || ctx->H.off_bvh_triangles != 0;
-    const bool staged = scene_bytes <= RM_LDS_SCENE_LIMIT_BYTES && !ctx->force_unstaged && !bvh;
-    if (m.waves == 0 || !staged) { m.waves = staged ? 1 : 4; m.per_wave = 1; }
-    const size_t lds = ((staged ? (size_t)ctx->H.total_words : 0u) + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
+    rm_kernel_choice k;
+    rm_status st = choose_kernel(ctx, p, &k);
+    if (st != RM_OK) return st;
+    const rm_launch_mode m = k.mode;
+    const size_t lds = k.lds_bytes;
     const dim3 block(m.waves * 64);
-
-    // The walk descends into the refracted child directly and parks the reflected one:
-    // at most one pending sibling per level below the cap, i.e. max_depth - 1 entries.
-    const int stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
-    const int pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
-
-    const bool fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
-    const void *fn = nullptr;
-    if (!staged) fn = bvh ? pick_unstaged<true>(stack, pow_mode, fast) : pick_unstaged<false>(stack, pow_mode, fast);
-    else if (m.waves == 1 && m.per_wave == 1) fn = pick_static<1, 1>(stack, pow_mode, fast);
-    else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE (this build keeps s1x1 only; "
-                                                  "the other geometries are in profiles/r01_ab_launch_modes.txt)");
+    const void *fn = k.fn;
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
     const dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
     if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging
@@ -637,6 +666,8 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     rm_band band;
     rm_status st = check_params(ctx, params, &band);
     if (st != RM_OK) return st;
+    if (params->flags & (RM_FLAG_F64_COMPACT | RM_FLAG_U8_COMPACT))
+        return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render: the packed layouts are for rm_render_device* (caller-owned device buffers)");
     RM_HIP(ctx, hipSetDevice(ctx->device));
 
     const size_t need = (size_t)params->frame_width * params->frame_height * 3u * sizeof(double);
@@ -682,6 +713,22 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
         timing->d2h_ms = d2h_ms;
         timing->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
+    return RM_OK;
+}
+
+rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t buflen) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_kernel_name: NULL ctx");
+    if (!buf || buflen == 0) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_kernel_name: NULL buffer");
+    rm_band band;
+    rm_status st = check_params(ctx, params, &band);
+    if (st != RM_OK) return st;
+    if (params->max_depth == 0) { std::snprintf(buf, buflen, "rm_fill_band_kernel"); return RM_OK; }
+    rm_kernel_choice k;
+    st = choose_kernel(ctx, params, &k);
+    if (st != RM_OK) return st;
+    // the name rocprofv3's kernel trace shows (template arguments in declaration order)
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+                  k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false");
     return RM_OK;
 }
 

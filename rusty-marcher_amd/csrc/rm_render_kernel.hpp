@@ -50,7 +50,7 @@ struct KernelArgs {
     uint32_t n_tiles;                        // 16 * patches in the band
     uint32_t order_mul;                      // dispatch order: tile = (id * order_mul + order_add) % n_tiles
     uint32_t order_add;
-    uint32_t _pad;
+    uint32_t f64_compact;                    // RM_FLAG_F64_COMPACT: frame holds only the owned rows, packed
     uint8_t *frame8;                         // optional [H][W][3] u8 display frame (NULL: not written)
     unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
 };
@@ -84,7 +84,8 @@ __device__ __forceinline__ void stage_scene(const double *__restrict__ scene_blo
 
 // tile id -> pixel origin.  Patch-major: patch = id / 16 walks the band row by row
 // (renderer.rs:69-70), sub = id % 16 walks the 4x4 tiles of the patch.
-__device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, uint32_t &tx0, uint32_t &ty0, uint32_t &ty8) {
+__device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, uint32_t &tx0, uint32_t &ty0, uint32_t &tyf,
+                                            uint32_t &ty8) {
     // Workgroups are dispatched in id order; the affine map (a bijection: order_mul is
     // coprime with n_tiles) decides which part of the image is rendered when.
     // (natural and bottom-up order, the two that ship, without the 64-bit modulo)
@@ -97,7 +98,9 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, ui
     tx0 = pcol * 32u + (sub & (32u / TILE_W - 1u)) * TILE_W;
     const uint32_t in_patch = (sub / (32u / TILE_W)) * TILE_H;
     ty0 = (a.patch_row_begin + prow * a.patch_row_stride) * 32u + in_patch;
-    ty8 = a.u8_compact ? prow * 32u + in_patch : ty0;           // row of the tile in the u8 frame
+    const uint32_t packed = prow * 32u + in_patch;               // row of the tile among the owned rows
+    tyf = a.f64_compact ? packed : ty0;                          // ... in the f64 frame
+    ty8 = a.u8_compact ? packed : ty0;                           // ... in the u8 frame
 }
 
 }  // namespace rmdev

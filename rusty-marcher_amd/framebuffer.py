@@ -14,16 +14,22 @@ class FrameBuffer:
         self.buffer = np.zeros((self.height, self.width, 3), dtype=np.float64)   # framebuffer.rs:12-22
 
     def _post(self, normalize, want_u8):
-        import torch
+        # The frame goes to the device through the library's own synchronous copies
+        # (rm_buffer_write returns when the bytes have landed), so rm_postprocess -- which
+        # runs on the context's stream, not on torch's -- can never read a frame still in flight.
         ctx = backend.default_context()
-        dev = torch.from_numpy(self.buffer).to("cuda:%d" % ctx.device)
-        out8 = np.empty(self.height * self.width * 3, dtype=np.uint8) if want_u8 else None
-        mx = C.c_double(0.)
-        _lib.check(_lib.lib().rm_postprocess(
-            ctx.ptr, C.c_void_p(dev.data_ptr()), self.width, self.height, 1 if normalize else 0,
-            out8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None, C.byref(mx)), ctx.ptr)
-        if normalize:
-            self.buffer[...] = dev.cpu().numpy()
+        dev = ctx.buffer_alloc(self.buffer.nbytes)
+        try:
+            ctx.buffer_write(dev, self.buffer)
+            out8 = np.empty(self.height * self.width * 3, dtype=np.uint8) if want_u8 else None
+            mx = C.c_double(0.)
+            _lib.check(_lib.lib().rm_postprocess(
+                ctx.ptr, dev, self.width, self.height, 1 if normalize else 0,
+                out8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_u8 else None, C.byref(mx)), ctx.ptr)
+            if normalize:
+                ctx.buffer_read(dev, self.buffer)
+        finally:
+            ctx.buffer_free(dev)
         return out8
 
     def normalize(self):

@@ -3,11 +3,14 @@
 // Rust host's interactive loop (main.rs:75-78 offset_camera -> main.rs:329-333 render ->
 // main.rs:337-346 to_vec into the pixbuf) becomes with rm_camera_update + rm_frame_submit.
 //
-//   rm_walk --rank R --world N --id-file PATH [--device D] [--frames K] [--step dx,dy,dz]
-//           [--width W] [--height H] [--depth D] [--fov F] [--fast-fp] [--out PREFIX]
+//   rm_walk --rank R --world N --id-file PATH [--run-id TEXT] [--device D] [--frames K]
+//           [--step dx,dy,dz] [--width W] [--height H] [--depth D] [--fov F] [--fast-fp] [--out PREFIX]
 //
 // Rank 0 creates the RCCL unique id and publishes it through PATH (written to PATH.tmp,
-// then renamed); the other ranks wait for the file.  Every rank renders its cyclic share
+// then renamed); the other ranks wait for the file.  The file starts with the launcher's
+// --run-id (every rank gets the same one) and a file whose run id differs -- one left behind
+// by an earlier run -- is ignored, so a rank that starts before rank 0 cannot join with a
+// stale id; rank 0 also removes whatever is at PATH before it publishes.  Every rank renders its cyclic share
 // of every frame; rank 0, the consumer, receives the display bytes of the whole frame and
 // (copied to page-locked host memory as part of the frame) and writes PREFIX_%04d.ppm (the
 // bytes of fb.to_vec(), not normalised -- what the UI blits).
@@ -34,13 +37,14 @@ int main(int argc, char **argv) {
     double fov = 1.5;
     rm_vec3 step{0., 0., -0.5};
     bool fast = false, use_rccl = true;
-    std::string id_file, out;
+    std::string id_file, out, run_id = "rm_walk";
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (!std::strcmp(argv[i], "--rank")) rank = std::atoi(next());
         else if (!std::strcmp(argv[i], "--world")) world = std::atoi(next());
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next());
         else if (!std::strcmp(argv[i], "--id-file")) id_file = next();
+        else if (!std::strcmp(argv[i], "--run-id")) run_id = next();
         else if (!std::strcmp(argv[i], "--frames")) frames = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--width")) width = (unsigned)std::strtoul(next(), nullptr, 10);
         else if (!std::strcmp(argv[i], "--height")) height = (unsigned)std::strtoul(next(), nullptr, 10);
@@ -50,7 +54,7 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--fast-fp")) fast = true;
         else if (!std::strcmp(argv[i], "--no-rccl")) use_rccl = false;
         else if (!std::strcmp(argv[i], "--out")) out = next();
-        else { std::fprintf(stderr, "usage: rm_walk --rank R --world N --id-file PATH [--device D] [--frames K] [--step dx,dy,dz] [--width W] [--height H] [--depth D] [--fov F] [--fast-fp] [--no-rccl] [--out PREFIX]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rm_walk --rank R --world N --id-file PATH [--run-id TEXT] [--device D] [--frames K] [--step dx,dy,dz] [--width W] [--height H] [--depth D] [--fov F] [--fast-fp] [--no-rccl] [--out PREFIX]\n"); return 2; }
     }
     if (world < 1 || rank < 0 || rank >= world) { std::fprintf(stderr, "need 0 <= rank < world\n"); return 2; }
     if (world > 1 && id_file.empty()) { std::fprintf(stderr, "--world > 1 needs --id-file\n"); return 2; }
@@ -70,12 +74,15 @@ int main(int argc, char **argv) {
     // ---- communicator: the id goes through a file
     if (world > 1 || use_rccl) {
         unsigned char id[RM_COMM_ID_BYTES];
+        char tag[64] = {};                                              // fixed-size run id in front of the unique id
+        std::snprintf(tag, sizeof tag, "%s", run_id.c_str());
         if (rank == 0) {
+            if (!id_file.empty()) std::remove(id_file.c_str());        // nothing of an earlier run survives rank 0's start
             CHECK(ctx, rm_comm_unique_id(id));
             if (!id_file.empty()) {
                 const std::string tmp = id_file + ".tmp";
                 FILE *f = std::fopen(tmp.c_str(), "wb");
-                if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+                if (!f || std::fwrite(tag, 1, sizeof tag, f) != sizeof tag || std::fwrite(id, 1, sizeof id, f) != sizeof id) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
                 std::fclose(f);
                 if (std::rename(tmp.c_str(), id_file.c_str()) != 0) { std::fprintf(stderr, "cannot publish %s\n", id_file.c_str()); return 1; }
             }
@@ -83,7 +90,9 @@ int main(int argc, char **argv) {
             bool got = false;
             for (int tries = 0; tries < 600 && !got; tries++) {                 // up to a minute
                 if (FILE *f = std::fopen(id_file.c_str(), "rb")) {
-                    got = std::fread(id, 1, sizeof id, f) == sizeof id;
+                    char seen[sizeof tag];
+                    got = std::fread(seen, 1, sizeof seen, f) == sizeof seen && !std::memcmp(seen, tag, sizeof tag) &&
+                          std::fread(id, 1, sizeof id, f) == sizeof id;             // another run's file: keep waiting
                     std::fclose(f);
                 }
                 if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));

@@ -20,7 +20,7 @@ extern "C" const char *rm_last_error(const rm_ctx *) { return rm_get_host_error(
 // a child box contains the boxes of everything below it (with the builder's inflation).
 static void walk_hierarchy(const rm_bvh &h, const std::vector<rm_aabb> &boxes, uint64_t ref, const double *box,
                            uint32_t leaf_size, std::vector<int> &seen, int depth) {
-    assert(depth < 64);
+    assert(depth <= (int)h.depth && h.depth <= RM_BVH_MAX_DEPTH);     // the kernel's stack: 64 entries, one per level
     const uint32_t idx = (uint32_t)ref, cnt = (uint32_t)(ref >> 32);
     if (cnt) {                                                          // leaf
         assert(cnt <= leaf_size && (size_t)idx + cnt <= boxes.size());
@@ -123,6 +123,23 @@ int main(int argc, char **argv) {
         if (st == RM_OK) n_ok++;
         else assert(std::strlen(rm_last_error(nullptr)) > 0);
         rm_scene_free(b);
+    }
+    // Spheres whose radii double along a line: the surface-area split peels one off per level
+    // (depth ~ count); the builder must switch to median splits and stay under the stack bound.
+    for (uint32_t leaf : {1u, 2u, 4u}) {
+        const uint32_t n = 400;
+        std::vector<rm_aabb> boxes(n);
+        double x = 0., r = 1e-30;
+        for (uint32_t i = 0; i < n; i++) {
+            x += 3. * r;
+            for (int a = 0; a < 3; a++) { boxes[i].lo[a] = (a == 0 ? x : 0.) - r; boxes[i].hi[a] = (a == 0 ? x : 0.) + r; }
+            r *= 2.;
+        }
+        const rm_bvh h = rm_build_bvh(boxes, leaf);
+        assert(h.depth > RM_BVH_SAH_DEPTH && h.depth <= RM_BVH_SAH_DEPTH + 10u);
+        std::vector<int> seen(n, 0);
+        walk_hierarchy(h, boxes, 0, nullptr, leaf, seen, 0);
+        for (int c : seen) assert(c == 1);
     }
     check_hierarchy(1, 4);
     check_hierarchy(5, 4);

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound(pkg, entry):
 
 def test_abi_version_and_build_info(pkg):
     L = pkg.lib()
-    assert L.rm_abi_version() == 1
+    assert L.rm_abi_version() == 2            # 2: rm_frame_submit_f64, rm_frame_wait_for, rm_frame_timing, rm_comm_info, rm_buffer_write
     info = L.rm_build_info().decode()
     assert "gfx950" in info
 
@@ -36,7 +36,7 @@ def test_struct_layout(pkg, entry, tmp_path):
     import subprocess
     B = pkg._lib
     names = ["rm_vec3", "rm_reflectance", "rm_light", "rm_sphere", "rm_polygon", "rm_triangle",
-             "rm_shape_ref", "rm_scene_desc", "rm_params", "rm_timing"]
+             "rm_shape_ref", "rm_scene_desc", "rm_params", "rm_timing", "rm_frame_times"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "rusty_marcher_amd.h"\nint main(void){' +
                    "".join('printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}\n")
@@ -126,3 +126,8 @@ def test_exchange_layout_and_comm_entry_points_without_a_gpu(pkg):
     assert L.rm_host_alloc(None, 16, None) == E
     L.rm_host_free(None, None)
     assert L.rm_frame_submit_to_host(None, None, None, None, None, None, 0) == E
+    assert L.rm_frame_submit_f64(None, None, None, None, 0) == E
+    assert L.rm_frame_wait_for(None, 0, 10) == E
+    assert L.rm_frame_timing(None, 0, None) == E
+    assert L.rm_comm_info(None, None, None, None) == E
+    assert L.rm_buffer_write(None, None, None, 0) == E

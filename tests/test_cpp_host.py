@@ -86,7 +86,7 @@ def test_rm_walk_camera_walk_matches_oracle(entry, O, tmp_path, rccl):
            "--id-file", str(tmp_path / "id.bin")] + ([] if rccl else ["--no-rccl"])
     log = subprocess.check_output(cmd).decode()
     assert "%d frames on 1 GPU(s)" % frames in log
-    assert os.path.exists(tmp_path / "id.bin") == rccl and (not rccl or os.path.getsize(tmp_path / "id.bin") == 128)
+    assert os.path.exists(tmp_path / "id.bin") == rccl and (not rccl or os.path.getsize(tmp_path / "id.bin") == 64 + 128)   # run id + ncclUniqueId
     rows = h // 32 * 32
     so = workloads.oracle_scene(O, "demo")
     for k in range(frames):

@@ -546,6 +546,20 @@ def test_hierarchy_walk_equals_flat_walk_bitwise(pkg, ctx, monkeypatch):
                                                                                     is_glass_like=(k % 5 == 0), refractive_index=1.3)))
     dup.lights.append(pkg.create_light(pkg.Vec3f(0., 10., 0.), pkg.Vec3f(1., 1., 1.), 1.))
     scenes.append(dup)
+    # spheres whose radii double along the view axis: a surface-area split peels one off per
+    # level (depth ~ count, beyond the wave's 64-entry stack); the builder must cap the depth
+    # (rm_bvh.hpp) and the image must still be the flat walk's
+    chain = pkg.Scene.new()
+    z, r = -1e-5, 1e-6
+    for k in range(100):
+        z -= 1.5 * r
+        chain.shapes.append(pkg.sphere.create(pkg.Vec3f(0.9 * r * (k % 3 - 1), 0.7 * r * (k % 5 - 2), z), r,
+                                              pkg.Reflectance(diffuse_color=(0.2 + 0.007 * k, 0.9 - 0.007 * k, 0.5),
+                                                              is_glass_like=(k % 3 == 0), refractive_index=1.2)))
+        z -= 1.5 * r
+        r *= 2.
+    chain.lights.append(pkg.create_light(pkg.Vec3f(5., 10., 5.), pkg.Vec3f(1., 1., 1.), 1.))
+    scenes.append(chain)
     monkeypatch.setenv("RM_DISABLE_BVH", "1")
     flat_ctx = pkg.backend.Context(0)
     monkeypatch.delenv("RM_DISABLE_BVH")
@@ -695,6 +709,88 @@ def test_frame_submit_through_rccl_world_of_one(pkg):
         torch.cuda.synchronize()
         assert torch.equal(f64[s], ref), "slot %d f64" % s
         assert torch.equal(d8[s], ref8[:n_rows * 32]) and torch.equal(g8[s], ref8[:n_rows * 32]), "slot %d u8" % s
+    cx.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 5, 8])
+def test_frame_submit_f64_layout_of_n_ranks_on_one_gpu(pkg, world):
+    """rm_frame_submit_f64: the f64 rows themselves travel (framebuffer.rs:6-22: the reference's
+    render target is f64).  Layout of `world` ranks without a transport, the ranks taking turns
+    on this GPU: each renders its cyclic rows PACKED into its chunk of the gather buffer, the
+    consumer's de-interleaved f64 frame must be the single-GPU frame bit for bit."""
+    import torch
+    c = workloads.CONFIGS["SHOT"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    n_rows = h // 32
+    cx = pkg.backend.Context(0)
+    cx.upload(pkg.Scene.create_default().flatten())
+    p = pkg.backend.make_params(1.5, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    cx.render_device(p, full.data_ptr())
+    torch.cuda.synchronize()
+    rows, chunk = cx.exchange_layout(p, world)
+    gathered = torch.full((world * chunk,), -3., dtype=torch.float64, device="cuda:0")
+    frame = torch.full((n_rows * 32, w, 3), -5., dtype=torch.float64, device="cuda:0")
+    for r in range(world):
+        cx.comm_init(r, world)
+        last = r == world - 1
+        cx.frame_submit_f64(p, gathered.data_ptr(), frame.data_ptr() if last else None, slot=r % 4)
+        cx.frame_wait(r % 4, timeout_ms=20000)
+        t = cx.frame_timing(r % 4)
+        assert 0. < t.kernel_ms <= t.total_ms and t.gather_ms >= 0.
+    assert torch.equal(frame, full[:n_rows * 32])
+    assert cx.comm_info() == (world - 1, world, 0)              # no transport: no communicator
+    cx.close()
+
+
+def test_frame_submit_f64_through_rccl_world_of_one(pkg):
+    """The same through a real communicator (of the one rank this box has), frames in flight
+    on all slots; what the communicator itself reports is echoed by rm_comm_info."""
+    import torch
+    c = workloads.CONFIGS["SHOT"]
+    w, h, depth = c["width"], c["height"], c["max_depth"]
+    n_rows = h // 32
+    cx = pkg.backend.Context(0)
+    cx.upload(pkg.Scene.create_default().flatten())
+    cx.comm_init(0, 1, pkg.backend.Context.comm_unique_id())
+    assert cx.comm_info() == (0, 1, 1)
+    p = pkg.backend.make_params(1.5, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    g = [torch.zeros((n_rows * 32, w, 3), dtype=torch.float64, device="cuda:0") for _ in range(4)]
+    f = [torch.zeros((n_rows * 32, w, 3), dtype=torch.float64, device="cuda:0") for _ in range(4)]
+    cams = [(0., 0., 0.), (0., 5., 0.), (-5., 0., 0.), (0., 0., -5.)]
+    for k, cam in enumerate(cams):
+        cx.set_camera(cam)
+        cx.frame_submit_f64(p, g[k].data_ptr(), f[k].data_ptr(), slot=k)
+    ref = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    for k, cam in enumerate(cams):
+        cx.frame_wait(k)
+        cx.set_camera(cam)
+        cx.render_device(p, ref.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(f[k], ref[:n_rows * 32]) and torch.equal(g[k], ref[:n_rows * 32]), "slot %d" % k
+    cx.close()
+
+
+def test_frame_wait_is_bounded(pkg):
+    """rm_frame_wait_for gives up with RM_ERR_TIMEOUT instead of hanging the host: here the
+    slot's stream is held up by a long render queued in front (8K frames), and a 1 ms bound
+    must come back as a status; a generous bound then completes."""
+    import torch
+    cx = pkg.backend.Context(0)
+    cx.upload(workloads.product_scene(pkg, "synthetic256").flatten())
+    w, h = 4096, 4096
+    p = pkg.backend.make_params(1.5, float(h), float(w), 10)
+    f = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    g = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    cx.comm_init(0, 1)
+    for _ in range(3):
+        cx.frame_submit(p, f.data_ptr(), g.data_ptr(), None, slot=0)
+    with pytest.raises(pkg.BackendError) as e:
+        cx.frame_wait(0, timeout_ms=1)
+    assert e.value.status == pkg._lib.RM_ERR_TIMEOUT
+    torch.cuda.synchronize()
     cx.close()
 
 
