@@ -5,6 +5,7 @@
 set -u
 TAG=${1:-run}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+BENCH=${BENCH:-$R/bench.py}     # BENCH=build/old/bench.py profiles the bench of another tree
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -16,7 +17,7 @@ for grp in \
   "FETCH_SIZE" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sizes "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $BENCH --steps 5 --warmup 2 --no-cpu-baseline --no-sizes "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

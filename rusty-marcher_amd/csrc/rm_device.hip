@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -88,16 +89,12 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
 // This build instantiates one tile per wave only (1 wave per workgroup with the LDS scene
 // copy, 4 without); the other geometries were measured with earlier builds.
+static constexpr uint32_t RM_CULL_MIN_PRIMS = 12;
+
 struct rm_launch_mode {
     int waves = 0;      // waves per workgroup; 0 = choose from the scene size at launch
     int per_wave = 1;   // tiles per wave
 };
-
-static bool parse_mode(const char *s, rm_launch_mode *m) {
-    int w = 0, t = 0;
-    if (std::sscanf(s, "s%dx%d", &w, &t) == 2) { m->waves = w; m->per_wave = t; return true; }
-    return false;
-}
 
 // dispatch order of the tiles (tile_origin): RM_TILE_ORDER = natural | reverse | hash
 enum { TILE_ORDER_NATURAL = 0, TILE_ORDER_REVERSE = 1, TILE_ORDER_HASH = 2 };
@@ -133,6 +130,11 @@ struct rm_ctx {
     // drain (1080p demo: 124 -> 116 us; hashed order 131 us).
     int tile_order = TILE_ORDER_REVERSE;
     bool disable_bvh = false;         // RM_DISABLE_BVH=1: brute-force walk (A/B knob)
+    // Ray bundles whose half-angle has at least this cosine cull primitives before a walk
+    // (rm_trace.inc); wider ones take the plain walk / the hierarchy.  RM_DISABLE_CULL=1 sets 2
+    // (never), RM_CULL_COS overrides (A/B knobs).
+    double cull_cos = 0.9;
+    uint32_t cull_min_prims = RM_CULL_MIN_PRIMS;   // RM_CULL_MIN (A/B knob)
     bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
 
@@ -181,33 +183,19 @@ static constexpr uint64_t RM_SCENE_MAX_WORDS = 0xFFFFFFF0ull;
 // is as fast: the demo scene has 4 spheres).
 static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 
-// Kernel instantiation table: stack depth x pow flavour for one launch geometry.
-template <int W, int T>
-static const void *pick_static(int stack, int pow_mode, bool fast) {
-#define RM_ROW(S)                                                                                    \
-    if (stack == S) {                                                                                \
-        if (fast)                                                                                    \
-            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, T>   \
-                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, T>;  \
-        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, T>     \
-                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, T>;    \
-    }
-    RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
-#undef RM_ROW
-    return nullptr;
-}
 
-// the same table for the unstaged kernels (scene blob read from global memory only),
-// without and with the wave-cooperative hierarchy walk
-template <bool BVH>
-static const void *pick_unstaged(int stack, int pow_mode, bool fast) {
+// Kernel instantiation table: stack depth x pow flavour for one launch geometry
+// (W waves per workgroup, one tile per wave; STAGED: LDS copy of the scene for the per-lane
+// gathers; BVH: hierarchy walk for wide bundles; CULL: bundle culling, rm_trace.inc).
+template <int W, bool STAGED, bool BVH, bool CULL>
+static const void *pick_kernel(int stack, int pow_mode, bool fast) {
 #define RM_ROW(S)                                                                                    \
     if (stack == S) {                                                                                \
         if (fast)                                                                                    \
-            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, 4, 1, false, BVH>   \
-                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, 4, 1, false, BVH>;  \
-        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, 4, 1, false, BVH>     \
-                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, 4, 1, false, BVH>;    \
+            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL>   \
+                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL>;  \
+        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL>     \
+                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL>;    \
     }
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
@@ -262,13 +250,9 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
-    if (const char *env = std::getenv("RM_KERNEL_MODE")) {
-        if (!parse_mode(env, &ctx->mode)) {
-            rm_set_host_error(std::string("rm_init: cannot parse RM_KERNEL_MODE=") + env);
-            rm_destroy(ctx);
-            return RM_ERR_INVALID_ARG;
-        }
-    }
+    if (const char *env = std::getenv("RM_DISABLE_CULL")) ctx->cull_cos = env[0] == '1' ? 2. : ctx->cull_cos;
+    if (const char *env = std::getenv("RM_CULL_COS")) ctx->cull_cos = std::atof(env);
+    if (const char *env = std::getenv("RM_CULL_MIN")) ctx->cull_min_prims = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
     return RM_OK;
 }
@@ -396,7 +380,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     // 32-bit word offsets: refuse scenes they cannot address
     const uint64_t need_words = (uint64_t)H.n_spheres * RM_SPHERE_WORDS + (uint64_t)H.n_polygons * RM_POLYGON_WORDS +
                                 ((uint64_t)n_pverts + 1u) * RM_PVERT_WORDS + (uint64_t)H.n_triangles * RM_TRIANGLE_WORDS +
-                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
+                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u + 4u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
                                 bvh_s.nodes.size() + bvh_t.nodes.size() + 256u;
     if (need_words > RM_SCENE_MAX_WORDS)
         return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, "rm_scene_upload: scene exceeds the 32 GiB the device layout can address");
@@ -409,6 +393,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.off_materials = take(n_prims * RM_MATERIAL_WORDS);
     H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
     H.off_keys = take((n_prims + 1u) / 2u);
+    H.off_bounds = take(n_prims * 4u);
     // The wave's hierarchy stack holds 64 entries, one parked sibling per level: the builder
     // keeps every tree under RM_BVH_MAX_DEPTH levels (rm_bvh.hpp); a tree that is deeper all
     // the same is not walked (its primitives keep their leaf order and are walked flat).
@@ -429,12 +414,49 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         m[8] = r.is_glass_like ? 1. : 0.;
         m[9] = 0.;
     };
+    // Bounding sphere of everything of primitive `pid` a ray can hit, for the bundle cull
+    // (rm_trace.inc): inflated by 1e-7 relative + 1e-9 of the coordinates' magnitude -- far
+    // beyond the rounding of any hit test, so a primitive some ray hits is never culled.
+    // Anything that is not a finite number makes the primitive a candidate for every bundle.
+    double max_normal = 1.;                                   // sphere normals are unit (sphere.rs:58)
+    auto put_bounds = [&](uint32_t pid, double cx, double cy, double cz, double r) {
+        double *w = &blob[H.off_bounds + 4u * pid];
+        const double mag = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);
+        double rr = r * (1. + 1e-7) + 1e-9 * (1. + mag);
+        if (!(rr >= 0.) || !std::isfinite(rr) || !std::isfinite(mag)) { cx = cy = cz = 0.; rr = std::numeric_limits<double>::infinity(); }
+        w[0] = cx; w[1] = cy; w[2] = cz; w[3] = rr;
+    };
+    // A planar primitive is hit where the ray meets the plane (point, normal) AND the x, y of
+    // that point pass the 2-D edge tests (polygon.rs:54-56, triangle.rs:69-77), i.e. lie in
+    // the convex hull of the vertices' x, y: the hit points are the hull of the vertices
+    // LIFTED onto that plane along z -- the vertices themselves when they are coplanar with
+    // it, as they are for everything the reference's constructors build.
+    auto planar_bounds = [&](uint32_t pid, const rm_vec3 &n, const rm_vec3 &pp, const rm_vec3 *v, uint32_t nv) {
+        max_normal = std::max(max_normal, std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z));
+        if (!(std::fabs(n.z) > 1e-12 * (std::fabs(n.x) + std::fabs(n.y) + std::fabs(n.z)))) {
+            // plane along z: the x, y of its points are a line; no finite bound holds the lifted hull
+            put_bounds(pid, 0., 0., 0., std::numeric_limits<double>::infinity());
+            return;
+        }
+        std::vector<rm_vec3> lifted(nv);
+        double cx = 0., cy = 0., cz = 0.;
+        for (uint32_t i = 0; i < nv; i++) {
+            const double z = pp.z - (n.x * (v[i].x - pp.x) + n.y * (v[i].y - pp.y)) / n.z;
+            lifted[i] = rm_vec3{v[i].x, v[i].y, z};
+            cx += v[i].x; cy += v[i].y; cz += z;
+        }
+        cx /= nv; cy /= nv; cz /= nv;
+        double r2 = 0.;
+        for (const rm_vec3 &q : lifted) r2 = std::max(r2, (q.x - cx) * (q.x - cx) + (q.y - cy) * (q.y - cy) + (q.z - cz) * (q.z - cz));
+        put_bounds(pid, cx, cy, cz, std::sqrt(r2));
+    };
     uint32_t pid = 0;
     for (uint32_t i = 0; i < H.n_spheres; i++, pid++) {
         const rm_sphere &s = d->spheres[sphere_src[i]];
         double *w = &blob[H.off_spheres + RM_SPHERE_WORDS * i];
         w[0] = s.center.x; w[1] = s.center.y; w[2] = s.center.z; w[3] = s.radius_square;
         put_material(pid, s.reflectance);
+        put_bounds(pid, s.center.x, s.center.y, s.center.z, std::sqrt(s.radius_square));
     }
     uint32_t pv = 0;
     for (uint32_t i = 0; i < H.n_polygons; i++, pid++) {
@@ -453,6 +475,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
             if (v < 4) { w[8 + 2 * v] = q.x; w[9 + 2 * v] = q.y; }
         }
         put_material(pid, p.reflectance);
+        planar_bounds(pid, p.plane_normal, p.plane_point, &d->polygon_vertices[p.first_vertex], p.n_vertices);
     }
     for (uint32_t i = 0; i < H.n_triangles; i++, pid++) {
         const rm_triangle &t = d->triangles[tri_src[i]];
@@ -461,7 +484,11 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         w[3] = t.center.x; w[4] = t.center.y; w[5] = t.center.z;
         for (int v = 0; v < 3; v++) { w[6 + 2 * v] = t.vertices[v].x; w[7 + 2 * v] = t.vertices[v].y; }
         put_material(pid, t.reflectance);
+        planar_bounds(pid, t.normal, t.center, t.vertices, 3u);
     }
+    // renderer.rs:168-172: a shadow ray starts 1e-3 of the normal off the hit point and runs
+    // along normalize(light - point): it passes within 1e-3 |normal| of the light
+    H.shadow_rho = 1e-3 * max_normal * (1. + 1e-6) + 1e-12;
     for (uint32_t l = 0; l < H.n_lights; l++) {
         const rm_light &lt = d->lights[l];
         double *w = &blob[H.off_lights + RM_LIGHT_WORDS * l];
@@ -535,29 +562,31 @@ struct rm_kernel_choice {
     rm_launch_mode mode;
     size_t lds_bytes = 0;
     int stack = 0, pow_mode = 0;
-    bool fast = false, staged = false, bvh = false;
+    bool fast = false, staged = false, bvh = false, cull = false;
 };
 
 static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice *k) {
-    // launch geometry: one tile per wave; small scenes get one wave per workgroup,
-    // larger ones share the LDS copy of the scene between four waves
-    rm_launch_mode m = ctx->mode;
+    // launch geometry: one tile per wave; small scenes get one wave per workgroup and an LDS
+    // copy of the scene for the per-lane gathers, larger ones four waves and none
     const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
+    const uint32_t n_prims = ctx->H.n_spheres + ctx->H.n_polygons + ctx->H.n_triangles;
     k->bvh = ctx->H.off_bvh_spheres != 0 || ctx->H.off_bvh_triangles != 0;
     k->staged = scene_bytes <= RM_LDS_SCENE_LIMIT_BYTES && !ctx->force_unstaged && !k->bvh;
-    if (m.waves == 0 || !k->staged) { m.waves = k->staged ? 1 : 4; m.per_wave = 1; }
-    k->mode = m;
-    k->lds_bytes = ((k->staged ? (size_t)ctx->H.total_words : 0u) + (size_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
+    // Bundle culling pays from about a dozen primitives on (a cull step costs about what two
+    // primitive tests cost); the six primitives of the demo scene are walked as they are.
+    k->cull = n_prims >= ctx->cull_min_prims || !k->staged;
+    k->mode.waves = k->staged ? 1 : 4;
+    k->mode.per_wave = 1;
+    k->lds_bytes = ((k->staged ? (size_t)ctx->H.total_words : 0u) + (size_t)k->mode.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
 
-    // The walk descends into the refracted child directly and parks the reflected one:
-    // at most one pending sibling per level below the cap, i.e. max_depth - 1 entries.
+    // A lane parks at most one sibling per level below the cap: max_depth - 1 entries.
     k->stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
     k->pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
     k->fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
-    if (!k->staged) k->fn = k->bvh ? pick_unstaged<true>(k->stack, k->pow_mode, k->fast) : pick_unstaged<false>(k->stack, k->pow_mode, k->fast);
-    else if (m.waves == 1 && m.per_wave == 1) k->fn = pick_static<1, 1>(k->stack, k->pow_mode, k->fast);
-    else return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: unsupported RM_KERNEL_MODE (this build keeps s1x1 only; "
-                                                  "the other geometries are in profiles/r01_ab_launch_modes.txt)");
+    k->fn = !k->staged ? (k->bvh ? pick_kernel<4, false, true, true>(k->stack, k->pow_mode, k->fast)
+                                 : pick_kernel<4, false, false, true>(k->stack, k->pow_mode, k->fast))
+          : k->cull    ? pick_kernel<1, true, false, true>(k->stack, k->pow_mode, k->fast)
+                       : pick_kernel<1, true, false, false>(k->stack, k->pow_mode, k->fast);
     return RM_OK;
 }
 
@@ -594,6 +623,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     a.n_tiles = n_rows * n_width * 16u;
     a.debug_stamps = nullptr;
     a.frame8 = d_frame8;
+    a.cull_cos = ctx->cull_cos;
     // dispatch order: tile = (id * order_mul + order_add) % n_tiles, a bijection
     a.order_mul = 1; a.order_add = 0;
     if (ctx->tile_order == TILE_ORDER_REVERSE && a.n_tiles > 1) {             // id -> n-1-id
@@ -727,8 +757,9 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     st = choose_kernel(ctx, params, &k);
     if (st != RM_OK) return st;
     // the name rocprofv3's kernel trace shows (template arguments in declaration order)
-    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
-                  k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false");
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+                  k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
+                  k.cull ? "true" : "false");
     return RM_OK;
 }
 

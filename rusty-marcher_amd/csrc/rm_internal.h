@@ -28,6 +28,9 @@ const char *rm_get_host_error();
 //   lights    8 words each : px py pz  cx cy cz  intensity 0
 //   keys      1 u32 per pid (2 per word): position in Scene.shapes order, used
 //                               only to break exact distance ties (shapes.rs:130)
+//   bounds    4 words per pid: centre and radius of a sphere holding every point of the
+//                               primitive a ray can hit (polygons: the vertices lifted onto
+//                               the plane the hit test uses), inflated by 1e-7 relative
 //   bvh       16 words per node (rm_bvh.hpp), one hierarchy over the spheres and one
 //                               over the triangles when there are enough of them; the
 //                               primitives of a kind are then stored in leaf order
@@ -38,7 +41,8 @@ struct rm_dev_header {
     uint32_t list_ordered;        // grouping by kind kept Scene.shapes order (no tie keys needed)
     uint32_t off_bvh_spheres;     // 0 = walk all spheres; else the sphere hierarchy (rm_bvh.hpp)
     uint32_t off_bvh_triangles;   // 0 = walk all triangles; else the triangle hierarchy
-    uint32_t _pad;
+    uint32_t off_bounds;          // bounding sphere per pid (centre, radius: 4 words), inflated -- the bundle cull reads these
+    double shadow_rho;            // every shadow ray passes within this of its light: 1e-3 x the longest normal (renderer.rs:168-172)
 };
 
 #define RM_SPHERE_WORDS 4u

@@ -21,6 +21,11 @@
 
 #define RM_BVH_NODE_WORDS 16u
 
+// waves per SIMD the integer-power kernels are compiled for (register budget 512 / this)
+#ifndef RM_MIN_WAVES
+#define RM_MIN_WAVES 4
+#endif
+
 namespace rmdev {
 
 // specular power flavours (see specular_pow in rm_trace.inc)
@@ -51,6 +56,7 @@ struct KernelArgs {
     uint32_t order_mul;                      // dispatch order: tile = (id * order_mul + order_add) % n_tiles
     uint32_t order_add;
     uint32_t f64_compact;                    // RM_FLAG_F64_COMPACT: frame holds only the owned rows, packed
+    double cull_cos;                         // bundles at least this narrow cull primitives (> 1: never; RM_DISABLE_CULL)
     uint8_t *frame8;                         // optional [H][W][3] u8 display frame (NULL: not written)
     unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
 };
@@ -65,10 +71,17 @@ struct StackEntry {
     uint32_t depth, _pad;
 };
 
-// Per-wave LDS block behind the scene copy: level 0 of the ray stack (7 f64 columns + one
-// u32 column of 64 lanes) during the walk, then the transpose slab of the stores.
-#define RM_WAVE_BVH_STACK_WORDS (64u * 7u + 32u)    /* the wave's hierarchy stack: 64 u32 entries */
-#define RM_WAVE_LDS_WORDS (RM_WAVE_BVH_STACK_WORDS + 32u)
+// Per-wave LDS block behind the scene copy (8-byte words):
+//   [0, 448)    level 0 of the lanes' ray stacks: 7 f64 fields, one lane-contiguous column each
+//   [448, 480)  its u32 depth column
+//   [480, 512)  the wave's hierarchy stack: 64 u32 entries
+//   [512, 704)  the tile's pixel sums, [pixel][channel] -- read as they lie by the store phase
+//   [704, 736)  pairing table of the ray hand-over: 64 u32 entries
+#define RM_WAVE_L0_DEPTH_WORDS 448u
+#define RM_WAVE_BVH_STACK_WORDS 480u
+#define RM_WAVE_SUM_WORDS 512u
+#define RM_WAVE_PAIR_WORDS 704u
+#define RM_WAVE_LDS_WORDS 736u
 
 extern __shared__ double rm_lds[];
 
