@@ -25,8 +25,23 @@ print("rays handed over to idle lanes: %.1f %% of all rays; steps if every lane 
 for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 1000)):
     m = (steps >= lo) & (steps <= hi)
     print("  tiles with %d..%d steps: %5.1f %%  of wave time %5.1f %%" % (lo, hi, 100 * m.mean(), 100 * life[m].sum() / life.sum()))
+cs = (a[:, 3] & np.uint64(0xFFFF)).astype(np.float64)
+cand = ((a[:, 3] >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(np.float64)
+wide = ((a[:, 3] >> np.uint64(40)) & np.uint64(0xFFF)).astype(np.float64)
+narrow = (a[:, 3] >> np.uint64(52)).astype(np.float64)
+if cs.sum() > 0 or wide.sum() > 0:
+    print("bundles per tile: %.2f narrow (culled), %.2f wide (plain walk / hierarchy); cull steps per narrow bundle %.2f; "
+          "candidates kept per narrow bundle %.2f" % (narrow.mean(), wide.mean(), cs.sum() / max(narrow.sum(), 1), cand.sum() / max(narrow.sum(), 1)))
+    one = steps == 1
+    print("  tiles with one step: candidates per bundle %.2f" % (cand[one].sum() / max(narrow[one].sum(), 1)))
 T = np.linspace(0, end.max(), 21)
 for lo, hi in zip(T[:-1], T[1:]):
     mid = (lo + hi) / 2
     occ = ((start <= mid) & (end > mid)).sum()
     print("t=%6.1f us  resident waves %5d  (%.2f per SIMD)" % (mid, occ, occ / 1024.0))
+if cs.sum() > 0:
+    for nb in (1, 2, 3):
+        m = narrow == nb
+        if m.any():
+            print("  tiles with %d narrow bundle(s): %5.1f %% of tiles, candidates per bundle: mean %.2f  p10 %.0f  p50 %.0f  p90 %.0f" % (
+                nb, 100 * m.mean(), (cand[m] / nb).mean(), *np.percentile(cand[m] / nb, [10, 50, 90])))

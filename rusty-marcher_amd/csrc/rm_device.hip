@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
 // This build instantiates one tile per wave only (1 wave per workgroup with the LDS scene
 // copy, 4 without); the other geometries were measured with earlier builds.
-static constexpr uint32_t RM_CULL_MIN_PRIMS = 12;
+static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4;
 
 struct rm_launch_mode {
     int waves = 0;      // waves per workgroup; 0 = choose from the scene size at launch
@@ -186,16 +186,17 @@ static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 
 // Kernel instantiation table: stack depth x pow flavour for one launch geometry
 // (W waves per workgroup, one tile per wave; STAGED: LDS copy of the scene for the per-lane
-// gathers; BVH: hierarchy walk for wide bundles; CULL: bundle culling, rm_trace.inc).
-template <int W, bool STAGED, bool BVH, bool CULL>
+// gathers; BVH: hierarchy walk for wide bundles; CULL: bundle culling, EDGES: its edge test
+// for planar primitives, rm_trace.inc).
+template <int W, bool STAGED, bool BVH, bool CULL, bool EDGES>
 static const void *pick_kernel(int stack, int pow_mode, bool fast) {
 #define RM_ROW(S)                                                                                    \
     if (stack == S) {                                                                                \
         if (fast)                                                                                    \
-            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL>   \
-                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL>;  \
-        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL>     \
-                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL>;    \
+            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES>   \
+                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES>;  \
+        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES>     \
+                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES>;    \
     }
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
@@ -380,7 +381,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     // 32-bit word offsets: refuse scenes they cannot address
     const uint64_t need_words = (uint64_t)H.n_spheres * RM_SPHERE_WORDS + (uint64_t)H.n_polygons * RM_POLYGON_WORDS +
                                 ((uint64_t)n_pverts + 1u) * RM_PVERT_WORDS + (uint64_t)H.n_triangles * RM_TRIANGLE_WORDS +
-                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u + 4u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
+                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u + 4u + 16u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
                                 bvh_s.nodes.size() + bvh_t.nodes.size() + 256u;
     if (need_words > RM_SCENE_MAX_WORDS)
         return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, "rm_scene_upload: scene exceeds the 32 GiB the device layout can address");
@@ -394,6 +395,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.off_lights = take(H.n_lights * RM_LIGHT_WORDS);
     H.off_keys = take((n_prims + 1u) / 2u);
     H.off_bounds = take(n_prims * 4u);
+    H.off_planar = take((H.n_polygons + H.n_triangles) * 16u);
     // The wave's hierarchy stack holds 64 entries, one parked sibling per level: the builder
     // keeps every tree under RM_BVH_MAX_DEPTH levels (rm_bvh.hpp); a tree that is deeper all
     // the same is not walked (its primitives keep their leaf order and are walked flat).
@@ -433,6 +435,18 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     // it, as they are for everything the reference's constructors build.
     auto planar_bounds = [&](uint32_t pid, const rm_vec3 &n, const rm_vec3 &pp, const rm_vec3 *v, uint32_t nv) {
         max_normal = std::max(max_normal, std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z));
+        double *pl = &blob[H.off_planar + 16u * (pid - H.n_spheres)];   // zero-filled: count 0 = no edge test
+        // The inside test reads only x and y (polygon.rs:54-56): with every vertex at the SAME x
+        // (or the same y) its cross products are differences of the same rounded products, sum to
+        // zero exactly and can never all be positive -- the primitive is never hit (the floor and
+        // ceiling of the Cornell box, any wall along z).  Radius -1: the cull drops it outright.
+        bool same_x = true, same_y = true;
+        for (uint32_t i = 1; i < nv; i++) { same_x = same_x && v[i].x == v[0].x; same_y = same_y && v[i].y == v[0].y; }
+        if (same_x || same_y) {
+            double *w = &blob[H.off_bounds + 4u * pid];
+            w[0] = w[1] = w[2] = 0.; w[3] = -1.;
+            return;
+        }
         if (!(std::fabs(n.z) > 1e-12 * (std::fabs(n.x) + std::fabs(n.y) + std::fabs(n.z)))) {
             // plane along z: the x, y of its points are a line; no finite bound holds the lifted hull
             put_bounds(pid, 0., 0., 0., std::numeric_limits<double>::infinity());
@@ -449,6 +463,17 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         double r2 = 0.;
         for (const rm_vec3 &q : lifted) r2 = std::max(r2, (q.x - cx) * (q.x - cx) + (q.y - cy) * (q.y - cy) + (q.z - cz) * (q.z - cz));
         put_bounds(pid, cx, cy, cz, std::sqrt(r2));
+        // the lifted vertices for the cull's edge test (triangles and quads; a triangle
+        // repeats its first vertex so that edge 2-3 closes it)
+        bool finite = true;
+        for (const rm_vec3 &q : lifted) finite = finite && std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z);
+        if (finite && (nv == 3u || nv == 4u)) {
+            for (uint32_t i = 0; i < 4u; i++) {
+                const rm_vec3 &q = lifted[i < nv ? i : 0u];
+                pl[3 * i] = q.x; pl[3 * i + 1] = q.y; pl[3 * i + 2] = q.z;
+            }
+            pl[12] = (double)nv;
+        }
     };
     uint32_t pid = 0;
     for (uint32_t i = 0; i < H.n_spheres; i++, pid++) {
@@ -562,7 +587,7 @@ struct rm_kernel_choice {
     rm_launch_mode mode;
     size_t lds_bytes = 0;
     int stack = 0, pow_mode = 0;
-    bool fast = false, staged = false, bvh = false, cull = false;
+    bool fast = false, staged = false, bvh = false, cull = false, edges = false;
 };
 
 static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice *k) {
@@ -583,10 +608,14 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice
     k->stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
     k->pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
     k->fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
-    k->fn = !k->staged ? (k->bvh ? pick_kernel<4, false, true, true>(k->stack, k->pow_mode, k->fast)
-                                 : pick_kernel<4, false, false, true>(k->stack, k->pow_mode, k->fast))
-          : k->cull    ? pick_kernel<1, true, false, true>(k->stack, k->pow_mode, k->fast)
-                       : pick_kernel<1, true, false, false>(k->stack, k->pow_mode, k->fast);
+    // the cull's edge test for planar primitives where there are several of them
+    k->edges = k->cull && ctx->H.n_polygons + ctx->H.n_triangles >= RM_CULL_EDGES_MIN_PLANAR;
+    const int st = k->stack, pw = k->pow_mode;
+    const bool f = k->fast;
+    k->fn = !k->staged ? (k->bvh ? (k->edges ? pick_kernel<4, false, true, true, true>(st, pw, f) : pick_kernel<4, false, true, true, false>(st, pw, f))
+                                 : (k->edges ? pick_kernel<4, false, false, true, true>(st, pw, f) : pick_kernel<4, false, false, true, false>(st, pw, f)))
+          : k->cull    ? (k->edges ? pick_kernel<1, true, false, true, true>(st, pw, f) : pick_kernel<1, true, false, true, false>(st, pw, f))
+                       : pick_kernel<1, true, false, false, false>(st, pw, f);
     return RM_OK;
 }
 
@@ -757,9 +786,9 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     st = choose_kernel(ctx, params, &k);
     if (st != RM_OK) return st;
     // the name rocprofv3's kernel trace shows (template arguments in declaration order)
-    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
-                  k.cull ? "true" : "false");
+                  k.cull ? "true" : "false", k.edges ? "true" : "false");
     return RM_OK;
 }
 

@@ -31,6 +31,9 @@ const char *rm_get_host_error();
 //   bounds    4 words per pid: centre and radius of a sphere holding every point of the
 //                               primitive a ray can hit (polygons: the vertices lifted onto
 //                               the plane the hit test uses), inflated by 1e-7 relative
+//   planar    16 words per polygon / triangle: up to four vertices lifted onto the plane of the
+//                               hit test (a triangle repeats its first), the vertex count
+//                               (0: no edge test -- more than four vertices, or no finite lift)
 //   bvh       16 words per node (rm_bvh.hpp), one hierarchy over the spheres and one
 //                               over the triangles when there are enough of them; the
 //                               primitives of a kind are then stored in leaf order
@@ -42,6 +45,8 @@ struct rm_dev_header {
     uint32_t off_bvh_spheres;     // 0 = walk all spheres; else the sphere hierarchy (rm_bvh.hpp)
     uint32_t off_bvh_triangles;   // 0 = walk all triangles; else the triangle hierarchy
     uint32_t off_bounds;          // bounding sphere per pid (centre, radius: 4 words), inflated -- the bundle cull reads these
+    uint32_t off_planar;          // per polygon / triangle (pid - n_spheres): lifted vertices + count, 16 words (cull_step)
+    uint32_t _pad;
     double shadow_rho;            // every shadow ray passes within this of its light: 1e-3 x the longest normal (renderer.rs:168-172)
 };
 

@@ -573,6 +573,57 @@ def test_hierarchy_walk_equals_flat_walk_bitwise(pkg, ctx, monkeypatch):
         flat_ctx.close()
 
 
+def test_bundle_cull_equals_plain_walk_bitwise(pkg, ctx, monkeypatch):
+    """The ray-bundle cull (rm_trace.inc: cone of the wave's rays against bounding spheres and,
+    for planar primitives, the planes through the apex and their edges) only decides WHICH
+    primitives a wave tests: with it switched off (RM_DISABLE_CULL=1: every bundle counts as
+    wide) the image must be the same bit for bit.  Scenes: the Cornell box from its corner (the
+    camera lies IN the planes of floor and wall, and floor / ceiling can never be hit: all
+    vertices at one y), the 256 spheres, the demo scene forced through the cull kernel
+    (RM_CULL_MIN=1), random meshes + polygons + spheres seen from inside, cameras on the move."""
+    rng = np.random.default_rng(23)
+    mixed = pkg.Scene.new()
+    tri = (rng.uniform(-20., 20., size=(60, 1, 3)) + rng.uniform(-4., 4., size=(60, 3, 3))).reshape(60, 9)
+    mixed.shapes.append(pkg.obj.Obj(tri))
+    for k in range(10):
+        c = rng.uniform(-15., 15., 3)
+        quad = [c + np.array(v) for v in ((3., 0., 1.), (0., 3., -1.), (-3., 0., 1.), (0., -3., -1.))]   # not planar: lifted
+        mixed.shapes.append(pkg.polygon.ConvexPolygon.create([pkg.Vec3f(*q) for q in quad],
+                                                             pkg.Reflectance(diffuse_color=(0.3, 0.8, 0.4), is_glass_like=(k % 2 == 0),
+                                                                             refractive_index=1.4, reflection=0.4)))
+    for k in range(12):
+        mixed.shapes.append(pkg.sphere.create(pkg.Vec3f(*rng.uniform(-12., 12., 3)), float(rng.uniform(0.5, 3.)),
+                                              pkg.Reflectance(diffuse_color=tuple(rng.uniform(0, 1, 3)), is_glass_like=(k % 3 == 0),
+                                                              refractive_index=1.5, reflection=0.3)))
+    mixed.lights.append(pkg.create_light(pkg.Vec3f(0., 0., 0.), pkg.Vec3f(1., 1., 1.), 1.))
+    mixed.lights.append(pkg.create_light(pkg.Vec3f(8., 30., 5.), pkg.Vec3f(1., .5, .5), .8))
+    jobs = [(workloads.product_scene(pkg, "cornell"), [(0., 0., 0.), (100., 100., 20.), (278., 273., -800.)]),
+            (workloads.product_scene(pkg, "synthetic256"), [(0., 0., 0.), (5., 2., -30.)]),
+            (pkg.Scene.create_default(), [(0., 0., 0.), (0., 5., 0.), (-5., 0., -10.)]),
+            (mixed, [(0., 0., 0.), (1., 2., 3.), (0., 0., 40.)])]
+    monkeypatch.setenv("RM_CULL_MIN", "1")
+    cull_ctx = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_DISABLE_CULL", "1")
+    plain_ctx = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_DISABLE_CULL")
+    monkeypatch.delenv("RM_CULL_MIN")
+    try:
+        lit = 0
+        for scene, cams in jobs:
+            for cam in cams:
+                scene.camera = pkg.Vec3f(*cam)
+                a, _ = gpu_render(pkg, cull_ctx, scene, 320, 224, 6)
+                b, _ = gpu_render(pkg, plain_ctx, scene, 320, 224, 6)
+                assert np.array_equal(a, b), "cull changed the image (camera %s)" % (cam,)
+                c, _ = gpu_render(pkg, ctx, scene, 320, 224, 6)     # the default context's choice of kernel
+                assert float(np.abs(a - c).max()) < 1e-12           # (it may sum a pixel's terms in another order)
+                lit += int((a.sum(axis=2) > 0).sum())
+        assert lit > 0
+    finally:
+        cull_ctx.close()
+        plain_ctx.close()
+
+
 # ---------------------------------------------------------------- properties at full size
 def test_bands_tile_the_frame_bitwise(pkg, ctx):
     """Row sharding: the union of per-rank bands is bit-identical to the
