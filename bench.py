@@ -584,6 +584,22 @@ def rank_main(args):
             host = {"value": w * h / med / 1e6, "unit": "Mpixels/s", "ms_per_frame": med * 1e3,
                     "kernel_ms": tm.kernel_ms, "d2h_ms": tm.d2h_ms,
                     "what": "rm_render(): kernel + device-to-host copy of the f64 frame into the caller's pageable memory, median of 10"}
+            # the same call into page-locked memory from rm_host_alloc -- what the Rust shim's
+            # staging buffer is
+            hp = C.c_void_p()
+            check(L.rm_host_alloc(ctx.ptr, host_frame.nbytes, C.byref(hp)))
+            pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_double)), shape=(h * w * 3,)).reshape(h, w, 3)
+            ctx.render(p_host, pinned)
+            ts = []
+            for _ in range(10):
+                t1 = time.perf_counter()
+                tm = ctx.render(p_host, pinned)
+                ts.append(time.perf_counter() - t1)
+            med = float(np.median(ts))
+            host["into_page_locked_memory"] = {"value": w * h / med / 1e6, "ms_per_frame": med * 1e3, "kernel_ms": tm.kernel_ms,
+                                               "d2h_ms": tm.d2h_ms, "identical": bool(np.array_equal(pinned, host_frame))}
+            del pinned
+            L.rm_host_free(ctx.ptr, hp)
             # the same frames with four in flight, each on a stream of its own (rm_frame_submit with no
             # communicator): what a renderer gets that need not wait for frame k before starting
             # k+1 -- the ramp and drain of one frame fill with the others.  Not the metric: a step

@@ -106,6 +106,7 @@ SIGNATURES = {
     "rm_destroy": (None, [_VP]),
     "rm_last_error": (C.c_char_p, [_VP]),
     "rm_scene_upload": (C.c_int, [_VP, _P(rm_scene_desc)]),
+    "rm_scene_uploads": (C.c_int, [_VP, _P(C.c_uint64), _P(C.c_uint64)]),
     "rm_camera_update": (C.c_int, [_VP, rm_vec3]),
     "rm_render": (C.c_int, [_VP, _P(rm_params), _P(C.c_double), _P(rm_timing)]),
     "rm_render_device": (C.c_int, [_VP, _P(rm_params), _VP, _VP]),

@@ -30,6 +30,12 @@ class Context:
         _lib.check(self.L.rm_scene_upload(self.ptr, C.byref(desc)), self.ptr)
         self._uploaded = desc_or_handle
 
+    def uploads(self):
+        """(calls of rm_scene_upload, copies it had to make)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.L.rm_scene_uploads(self.ptr, C.byref(a), C.byref(b)), self.ptr)
+        return a.value, b.value
+
     def set_camera(self, cam):
         _lib.check(self.L.rm_camera_update(self.ptr, _lib.vec3(cam)), self.ptr)
 

@@ -121,6 +121,8 @@ struct rm_ctx {
     double *d_scene = nullptr;
     size_t d_scene_words = 0;
     rm_vec3 camera{0., 0., 0.};
+    std::vector<double> host_blob;    // the device image of the resident scene (rm_scene_upload skips identical ones)
+    uint64_t upload_calls = 0, upload_copies = 0;
     bool integer_exponents = false;   // every material's specular_exponent is a small non-negative integer
     bool force_generic_pow = false;   // RM_FORCE_GENERIC_POW=1 (A/B knob)
     bool force_fast_fp = false;       // RM_FORCE_FAST_FP=1 (A/B knob; same as RM_FLAG_FAST_FP on every call)
@@ -525,8 +527,17 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     if (H.off_bvh_spheres) std::memcpy(&blob[H.off_bvh_spheres], bvh_s.nodes.data(), bvh_s.nodes.size() * sizeof(double));
     if (H.off_bvh_triangles) std::memcpy(&blob[H.off_bvh_triangles], bvh_t.nodes.data(), bvh_t.nodes.size() * sizeof(double));
 
+    // The reference's hosts hand the whole Scene to every render() call (main.rs:331-333);
+    // a scene whose device image is the one already resident is not copied again (a camera
+    // move is not part of the image: the camera travels as a kernel argument).
+    ctx->upload_calls++;
+    if (ctx->have_scene && blob == ctx->host_blob && std::memcmp(&H, &ctx->H, sizeof H) == 0) {
+        ctx->camera = d->camera;
+        return RM_OK;
+    }
     RM_HIP(ctx, hipSetDevice(ctx->device));
     RM_HIP(ctx, hipDeviceSynchronize());   // a render (on any stream: the caller's, a frame slot's) may still be reading the old blob
+    ctx->upload_copies++;
     if (ctx->d_scene_words < blob.size()) {
         if (ctx->d_scene) RM_HIP(ctx, hipFree(ctx->d_scene));
         ctx->d_scene = nullptr;
@@ -544,6 +555,14 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         int_exp = int_exp && (y >= 0. && y <= 1048576. && y == std::floor(y));
     }
     ctx->integer_exponents = int_exp;
+    ctx->host_blob.swap(blob);
+    return RM_OK;
+}
+
+rm_status rm_scene_uploads(rm_ctx *ctx, uint64_t *calls, uint64_t *copies) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_scene_uploads: NULL ctx");
+    if (calls) *calls = ctx->upload_calls;
+    if (copies) *copies = ctx->upload_copies;
     return RM_OK;
 }
 
@@ -743,20 +762,30 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
         ctx->frame_h = params->frame_height;
     }
 
+    // Device -> host overlapped with the render: the owned rows are rendered as a few launches
+    // (sub-bands of consecutive patch rows, bottom of the image first: those rows are the
+    // expensive ones), and while launch k+1 runs the rows of launch k cross the PCIe link.
+    // One launch for small frames and for strided bands (rows of several GPUs interleaved).
+    // One launch, then one copy.  The copy IS the call: 48.7 MB of f64 at 1080p take 0.87-0.93 ms
+    // at the 52-56 GB/s this PCIe link delivers device -> host, the kernel 0.09 ms.  Rendering
+    // in sub-bands and copying each while the next renders was measured and dropped
+    // (profiles/r02_host_copy.txt): four synchronous copies into pageable memory 0.984 ms, eight
+    // asynchronous ones into page-locked memory 1.04 ms, against 0.985 / 0.973 ms for this.
+    const size_t row_bytes = (size_t)params->frame_width * 3u * sizeof(double);
+    const uint32_t n_rows = band.count();
     RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     st = launch_render(ctx, params, band, ctx->d_frame, nullptr, ctx->stream);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     double d2h_ms = 0.;
-    if (host_rgb && band.count() > 0) {
+    if (host_rgb && n_rows > 0) {
         // Only the owned rows are copied: rows below the last whole patch row keep the
         // caller's previous contents, as in the reference (renderer.rs:53).
-        const size_t row_bytes = (size_t)params->frame_width * 3u * sizeof(double);
         RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const auto t0 = std::chrono::steady_clock::now();
-        const uint32_t run = band.stride == 1 ? band.count() : 1u;     // consecutive owned patch rows per copy
-        for (uint32_t k = 0; k < band.count(); k += run) {
+        const uint32_t run = band.stride == 1 ? n_rows : 1u;               // consecutive owned patch rows per copy
+        for (uint32_t k = 0; k < n_rows; k += run) {
             const size_t off = (size_t)(band.begin + k * band.stride) * 32u * row_bytes;
             RM_HIP(ctx, hipMemcpy((char *)host_rgb + off, (const char *)ctx->d_frame + off, (size_t)run * 32u * row_bytes,
                                   hipMemcpyDeviceToHost));

@@ -71,8 +71,13 @@ int main(int argc, char **argv) {
         r.max_depth = depth;
         if (fast) r.flags |= RM_FLAG_FAST_FP;
         std::string msg;
-        for (unsigned f = 0; f < frames; f++) msg = r.render(fb, sc);        // main.rs:329-333
-        std::printf("kernel %.3f ms, device->host %.3f ms\n", r.last_timing.kernel_ms, r.last_timing.d2h_ms);
+        for (unsigned f = 0; f < frames; f++) msg = r.render(fb, sc);        // main.rs:329-333: the whole Scene goes in every time
+        std::printf("kernel %.3f ms, device->host %.3f ms, call %.3f ms\n", r.last_timing.kernel_ms, r.last_timing.d2h_ms,
+                    r.last_timing.total_ms);
+        uint64_t up_calls = 0, up_copies = 0;
+        check(rm_scene_uploads(r.context(), &up_calls, &up_copies), r.context());
+        std::printf("scene uploads: %llu calls, %llu copies to the device\n", (unsigned long long)up_calls,
+                    (unsigned long long)up_copies);
         // main.rs:353-357 save_to_file: fb.normalize(); fb.write_ppm("out.ppm")
         const std::vector<uint8_t> rgb = renderer::to_vec(r, fb, normalize);
         renderer::write_ppm(out, fb, rgb);

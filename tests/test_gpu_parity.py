@@ -845,6 +845,35 @@ def test_frame_wait_is_bounded(pkg):
     cx.close()
 
 
+def test_upload_of_the_resident_scene_is_not_repeated_and_a_changed_one_is(pkg, O):
+    """rm_scene_upload compares the device image it builds with the resident one: the same
+    scene again (any camera) costs no copy; any change of a primitive, material or light does,
+    and the next frame shows it.  rm_render's band-by-band device -> host overlap (frames of
+    8 MB and more) must deliver the same frame as the single-launch path."""
+    cx = pkg.backend.Context(0)
+    scene = pkg.Scene.create_default()
+    w, h, depth = 1920, 1080, 5
+    a, _ = gpu_render(pkg, cx, scene, w, h, depth)
+    assert cx.uploads() == (1, 1)
+    scene.camera = pkg.Vec3f(0., 5., 0.)
+    b, _ = gpu_render(pkg, cx, scene, w, h, depth)
+    assert cx.uploads() == (2, 1) and not np.array_equal(a, b)
+    so = O.OracleScene.create_default(); so.set_camera((0., 5., 0.))
+    compare(b, O.render(so, w, h, max_depth=depth))
+    scene.lights[1] = pkg.create_light(pkg.Vec3f(20., 20., 20.), pkg.Vec3f(1., .5, .5), 0.5)
+    c, _ = gpu_render(pkg, cx, scene, w, h, depth)
+    assert cx.uploads() == (3, 2) and not np.array_equal(b, c)
+    # the overlapped host copy against a device-resident render of the same frame
+    import torch
+    dev = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    cx.render_device(p, dev.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), c)
+    cx.close()
+
+
 def test_render_is_deterministic(pkg, ctx):
     c = workloads.CONFIGS["C2"]
     scene = pkg.Scene.create_default()
