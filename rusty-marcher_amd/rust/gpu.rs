@@ -100,41 +100,72 @@ pub struct RmTiming {
     pub total_ms: f64,
 }
 
+#[repr(C)]
+#[derive(Default)]
+pub struct RmFrameTimes {
+    pub kernel_ms: f64,
+    pub gather_ms: f64,
+    pub total_ms: f64,
+}
+
 pub enum RmScene {}
 pub enum RmCtx {}
 
+// Every entry point of include/rusty_marcher_amd.h, in its order (tests/test_rust_binding.py
+// checks names, arity and argument classes against the header).
 #[link(name = "rusty_marcher_amd")]
+#[allow(dead_code)]
 extern "C" {
+    fn rm_reflectance_default(out: *mut RmReflectance);
     fn rm_create_renderer(fov: f64, height: f64, width: f64, out: *mut RmParams);
     fn rm_scene_new(out: *mut *mut RmScene) -> c_int;
     fn rm_scene_free(scene: *mut RmScene);
-    fn rm_scene_add_sphere(s: *mut RmScene, c: RmVec3, radius: f64, r: *const RmReflectance) -> c_int;
-    fn rm_scene_add_polygon(s: *mut RmScene, v: *const RmVec3, n: u32, r: *const RmReflectance) -> c_int;
-    fn rm_scene_add_mesh(s: *mut RmScene, tri_xyz: *const f64, n_triangles: u32, offset: RmVec3) -> c_int;
-    fn rm_scene_offset_shape(s: *mut RmScene, shape_index: u32, offset: RmVec3) -> c_int;
-    fn rm_scene_add_light(s: *mut RmScene, position: RmVec3, color: RmVec3, intensity: f64) -> c_int;
-    fn rm_scene_set_camera(s: *mut RmScene, camera: RmVec3) -> c_int;
-    fn rm_scene_get_desc(s: *const RmScene, out: *mut RmSceneDesc) -> c_int;
-    fn rm_format_status(buf: *mut c_char, buflen: usize, ms: u64, w: u32, h: u32) -> c_int;
+    fn rm_scene_create_default(out: *mut *mut RmScene) -> c_int;
+    fn rm_scene_add_sphere(scene: *mut RmScene, center: RmVec3, radius: f64, r: *const RmReflectance) -> c_int;
+    fn rm_scene_add_polygon(scene: *mut RmScene, vertices: *const RmVec3, n_vertices: u32, r: *const RmReflectance) -> c_int;
+    fn rm_scene_add_mesh(scene: *mut RmScene, tri_xyz: *const f64, n_triangles: u32, offset: RmVec3) -> c_int;
+    fn rm_scene_add_light(scene: *mut RmScene, position: RmVec3, color: RmVec3, intensity: f64) -> c_int;
+    fn rm_scene_offset_shape(scene: *mut RmScene, shape_index: u32, offset: RmVec3) -> c_int;
+    fn rm_scene_set_camera(scene: *mut RmScene, camera: RmVec3) -> c_int;
+    fn rm_scene_offset_camera(scene: *mut RmScene, offset: RmVec3) -> c_int;
+    fn rm_scene_load_obj(scene: *mut RmScene, path: *const c_char, offset: RmVec3, n_models_out: *mut u32) -> c_int;
+    fn rm_scene_open_obj(path: *const c_char, out: *mut *mut RmScene) -> c_int;
+    fn rm_scene_get_desc(scene: *const RmScene, out: *mut RmSceneDesc) -> c_int;
+    fn rm_format_status(buf: *mut c_char, buflen: usize, ms: u64, frame_width: u32, frame_height: u32) -> c_int;
     fn rm_init(device_ordinal: c_int, out: *mut *mut RmCtx) -> c_int;
     fn rm_destroy(ctx: *mut RmCtx);
     fn rm_last_error(ctx: *const RmCtx) -> *const c_char;
     fn rm_scene_upload(ctx: *mut RmCtx, desc: *const RmSceneDesc) -> c_int;
-    fn rm_render(ctx: *mut RmCtx, p: *const RmParams, host_rgb: *mut f64, t: *mut RmTiming) -> c_int;
-    // interactive loop / several GPUs (one process per GPU): see host/rm_walk.cpp for the same
+    fn rm_scene_uploads(ctx: *mut RmCtx, calls: *mut u64, copies: *mut u64) -> c_int;
+    fn rm_camera_update(ctx: *mut RmCtx, camera: RmVec3) -> c_int;
+    fn rm_render(ctx: *mut RmCtx, params: *const RmParams, host_rgb: *mut f64, timing: *mut RmTiming) -> c_int;
+    fn rm_render_device(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    fn rm_render_device_u8(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_rgb8: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    fn rm_device_framebuffer(ctx: *mut RmCtx, device_rgb: *mut *mut c_void, bytes: *mut usize) -> c_int;
+    fn rm_postprocess(ctx: *mut RmCtx, device_rgb: *mut c_void, frame_width: u32, frame_height: u32, normalize: c_int, host_rgb8: *mut u8, max_out: *mut f64) -> c_int;
+    // interactive loop / several GPUs (one process per GPU): host/rm_walk.cpp is the same
     // sequence in C++ -- rm_camera_update between frames, up to 4 frames in flight
-    #[allow(dead_code)] fn rm_camera_update(ctx: *mut RmCtx, camera: RmVec3) -> c_int;
-    #[allow(dead_code)] fn rm_buffer_alloc(ctx: *mut RmCtx, bytes: usize, device_ptr: *mut *mut c_void) -> c_int;
-    #[allow(dead_code)] fn rm_buffer_free(ctx: *mut RmCtx, device_ptr: *mut c_void);
-    #[allow(dead_code)] fn rm_buffer_read(ctx: *mut RmCtx, device_ptr: *const c_void, host_dst: *mut c_void, bytes: usize) -> c_int;
-    #[allow(dead_code)] fn rm_comm_unique_id(id_out: *mut c_void) -> c_int; // 128 bytes
-    #[allow(dead_code)] fn rm_comm_init(ctx: *mut RmCtx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
-    #[allow(dead_code)] fn rm_exchange_layout(p: *const RmParams, world: c_int, rows_per_rank: *mut u32, chunk_bytes: *mut usize) -> c_int;
-    #[allow(dead_code)] fn rm_frame_submit(ctx: *mut RmCtx, p: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, slot: u32) -> c_int;
-    #[allow(dead_code)] fn rm_host_alloc(ctx: *mut RmCtx, bytes: usize, host_ptr: *mut *mut c_void) -> c_int;
-    #[allow(dead_code)] fn rm_host_free(ctx: *mut RmCtx, host_ptr: *mut c_void);
-    #[allow(dead_code)] fn rm_frame_submit_to_host(ctx: *mut RmCtx, p: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, host_display8: *mut c_void, slot: u32) -> c_int;
-    #[allow(dead_code)] fn rm_frame_wait(ctx: *mut RmCtx, slot: u32) -> c_int;
+    fn rm_buffer_alloc(ctx: *mut RmCtx, bytes: usize, device_ptr: *mut *mut c_void) -> c_int;
+    fn rm_buffer_free(ctx: *mut RmCtx, device_ptr: *mut c_void);
+    fn rm_buffer_read(ctx: *mut RmCtx, device_ptr: *const c_void, host_dst: *mut c_void, bytes: usize) -> c_int;
+    fn rm_buffer_write(ctx: *mut RmCtx, device_ptr: *mut c_void, host_src: *const c_void, bytes: usize) -> c_int;
+    fn rm_host_alloc(ctx: *mut RmCtx, bytes: usize, host_ptr: *mut *mut c_void) -> c_int;
+    fn rm_host_free(ctx: *mut RmCtx, host_ptr: *mut c_void);
+    fn rm_comm_unique_id(id_out: *mut c_void) -> c_int; // 128 bytes
+    fn rm_comm_init(ctx: *mut RmCtx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    fn rm_comm_destroy(ctx: *mut RmCtx);
+    fn rm_exchange_layout(params: *const RmParams, world: c_int, rows_per_rank: *mut u32, chunk_bytes: *mut usize) -> c_int;
+    fn rm_frame_submit(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, slot: u32) -> c_int;
+    fn rm_frame_submit_to_host(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, host_display8: *mut c_void, slot: u32) -> c_int;
+    fn rm_frame_wait(ctx: *mut RmCtx, slot: u32) -> c_int;
+    fn rm_frame_wait_for(ctx: *mut RmCtx, slot: u32, timeout_ms: u32) -> c_int;
+    fn rm_frame_submit_f64(ctx: *mut RmCtx, params: *const RmParams, device_gather64: *mut c_void, device_frame64: *mut c_void, slot: u32) -> c_int;
+    fn rm_frame_timing(ctx: *mut RmCtx, slot: u32, out: *mut RmFrameTimes) -> c_int;
+    fn rm_comm_info(ctx: *mut RmCtx, rank: *mut c_int, world: *mut c_int, n_communicators: *mut c_int) -> c_int;
+    fn rm_abi_version() -> u32;
+    fn rm_build_info() -> *const c_char;
+    fn rm_device_info(ctx: *mut RmCtx, name_buf: *mut c_char, buflen: usize, n_cus: *mut c_int, lds_bytes: *mut usize) -> c_int;
+    fn rm_kernel_name(ctx: *mut RmCtx, params: *const RmParams, buf: *mut c_char, buflen: usize) -> c_int;
 }
 
 /// The reference's failure mode on this path is a panic.
@@ -176,18 +207,19 @@ impl SceneSink {
     }
 }
 
-/// One GPU: context + reusable staging buffer.  Owned by `Renderer` (renderer.rs:17-23
-/// gains a `gpu: RefCell<Gpu>` field) or by `Win`.
+/// One GPU: context + a page-locked staging frame (rm_host_alloc).  Owned by `Renderer`
+/// (renderer.rs:17-23 gains a `gpu: RefCell<Gpu>` field) or by `Win`.
 pub struct Gpu {
     ctx: *mut RmCtx,
-    staging: Vec<f64>,
+    staging: *mut f64,
+    staging_len: usize,
 }
 
 impl Gpu {
     pub fn new(device: i32) -> Gpu {
         let mut ctx: *mut RmCtx = ptr::null_mut();
         check(unsafe { rm_init(device, &mut ctx) }, ptr::null());
-        Gpu { ctx, staging: Vec::new() }
+        Gpu { ctx, staging: ptr::null_mut(), staging_len: 0 }
     }
 
     /// Body of `Renderer::render` (renderer.rs:36-126) with the Rayon loop and the
@@ -205,7 +237,11 @@ impl Gpu {
             println!("Dimensions mismatch") // renderer.rs:49-51
         }
 
-        // flatten Scene -> rm_scene (shapes in list order: ties, shapes.rs:130)
+        // flatten Scene -> rm_scene (shapes in list order: ties, shapes.rs:130).  render() gets
+        // the whole Scene every call (main.rs:331-333), so the flat copy is rebuilt every call
+        // (microseconds for the reference's scenes); rm_scene_upload recognises a scene whose
+        // device image is already resident and copies nothing -- camera moves included, the
+        // camera is a kernel argument.
         let mut raw: *mut RmScene = ptr::null_mut();
         check(unsafe { rm_scene_new(&mut raw) }, ptr::null());
         {
@@ -231,27 +267,30 @@ impl Gpu {
         p.max_depth = 3; // renderer.rs:262
 
         // FrameBuffer.buffer is Vec<Vec<Vec3f>>: one allocation per row (framebuffer.rs:12-22),
-        // and Vec3f is not #[repr(C)].  Render into a flat staging buffer that first
-        // receives the current contents (rows below the last whole patch row must keep
-        // them, renderer.rs:53), then copy back.
+        // and Vec3f is not #[repr(C)]: render into a flat page-locked staging frame, then copy
+        // the RENDERED rows back.  rm_render writes whole patch rows only, so the rows below the
+        // last whole patch row keep their previous contents without being staged at all
+        // (renderer.rs:53).
         let n = frame.width * frame.height * 3;
-        self.staging.resize(n, 0.);
-        for (j, row) in frame.buffer.iter().enumerate() {
-            for (i, px) in row.iter().enumerate() {
-                let k = (j * frame.width + i) * 3;
-                self.staging[k] = px.x;
-                self.staging[k + 1] = px.y;
-                self.staging[k + 2] = px.z;
+        if n > self.staging_len {
+            if !self.staging.is_null() {
+                unsafe { rm_host_free(self.ctx, self.staging as *mut c_void) };
             }
+            let mut mem: *mut c_void = ptr::null_mut();
+            check(unsafe { rm_host_alloc(self.ctx, n * 8, &mut mem) }, self.ctx);
+            self.staging = mem as *mut f64;
+            self.staging_len = n;
         }
         let mut timing = RmTiming::default();
-        check(unsafe { rm_render(self.ctx, &p, self.staging.as_mut_ptr(), &mut timing) }, self.ctx);
-        for (j, row) in frame.buffer.iter_mut().enumerate() {
+        check(unsafe { rm_render(self.ctx, &p, self.staging, &mut timing) }, self.ctx);
+        let rendered_rows = (frame.height / 32) * 32;
+        let staged = unsafe { ::std::slice::from_raw_parts(self.staging, n) };
+        for (j, row) in frame.buffer.iter_mut().enumerate().take(rendered_rows) {
             for (i, px) in row.iter_mut().enumerate() {
                 let k = (j * frame.width + i) * 3;
-                px.x = self.staging[k];
-                px.y = self.staging[k + 1];
-                px.z = self.staging[k + 2];
+                px.x = staged[k];
+                px.y = staged[k + 1];
+                px.z = staged[k + 2];
             }
         }
 
@@ -267,6 +306,11 @@ impl Gpu {
 
 impl Drop for Gpu {
     fn drop(&mut self) {
-        unsafe { rm_destroy(self.ctx) }
+        unsafe {
+            if !self.staging.is_null() {
+                rm_host_free(self.ctx, self.staging as *mut c_void);
+            }
+            rm_destroy(self.ctx)
+        }
     }
 }
