@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
 // This build instantiates one tile per wave only (1 wave per workgroup with the LDS scene
 // copy, 4 without); the other geometries were measured with earlier builds.
-static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4;
+static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4, RM_CULL_MAX_PRIMS = 2048;
 
 struct rm_launch_mode {
     int waves = 0;      // waves per workgroup; 0 = choose from the scene size at launch
@@ -671,7 +671,10 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     a.n_tiles = n_rows * n_width * 16u;
     a.debug_stamps = nullptr;
     a.frame8 = d_frame8;
-    a.cull_cos = ctx->cull_cos;
+    // a cull step handles 64 primitives: beyond a few thousand the hierarchy walk is the
+    // cheaper way to find the few a bundle can reach (2 = no bundle is ever narrow enough)
+    const uint32_t n_prims_all = ctx->H.n_spheres + ctx->H.n_polygons + ctx->H.n_triangles;
+    a.cull_cos = n_prims_all > RM_CULL_MAX_PRIMS ? 2. : ctx->cull_cos;
     // dispatch order: tile = (id * order_mul + order_add) % n_tiles, a bijection
     a.order_mul = 1; a.order_add = 0;
     if (ctx->tile_order == TILE_ORDER_REVERSE && a.n_tiles > 1) {             // id -> n-1-id
