@@ -353,8 +353,11 @@ rm_status rm_frame_submit_f64(rm_ctx *ctx, const rm_params *params, void *device
                               uint32_t slot);
 
 /* Device times of the slot's last completed frame (call after rm_frame_wait): render kernel,
- * collective, and everything of the frame on its stream. */
+ * collective, and everything of the frame on its stream.  The stamps are three more events
+ * per frame in the slot's stream and are recorded only after rm_frame_timing_enable(ctx, 1)
+ * (a diagnostic: they cost a frame in flight ~15 us). */
 typedef struct rm_frame_times { double kernel_ms, gather_ms, total_ms; } rm_frame_times;
+rm_status rm_frame_timing_enable(rm_ctx *ctx, int on);
 rm_status rm_frame_timing(rm_ctx *ctx, uint32_t slot, rm_frame_times *out);
 
 /* What the communicator itself reports (ncclCommUserRank / ncclCommCount) and how many

@@ -2,7 +2,8 @@
 (layout of N ranks, no transport) with 1..4 frames in flight, on one GPU.  Shows what the
 slots' separate streams buy when a rank's share is too small to fill the chip for long.
 usage (GPU box): python3 profiles/slots_cost.py"""
-import sys, time
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per slot (HIP's default of 4 makes slots share)
 sys.path.insert(0, ".")
 import torch
 import __graft_entry__ as G, workloads

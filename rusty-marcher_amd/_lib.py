@@ -128,6 +128,7 @@ SIGNATURES = {
     "rm_frame_wait": (C.c_int, [_VP, C.c_uint32]),
     "rm_frame_wait_for": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     "rm_frame_submit_f64": (C.c_int, [_VP, _P(rm_params), _VP, _VP, C.c_uint32]),
+    "rm_frame_timing_enable": (C.c_int, [_VP, C.c_int]),
     "rm_frame_timing": (C.c_int, [_VP, C.c_uint32, _P(rm_frame_times)]),
     "rm_comm_info": (C.c_int, [_VP, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "rm_abi_version": (C.c_uint32, []),

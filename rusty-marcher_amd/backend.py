@@ -93,6 +93,9 @@ class Context:
         else:
             _lib.check(self.L.rm_frame_wait_for(self.ptr, slot, int(timeout_ms)), self.ptr)
 
+    def frame_timing_enable(self, on=True):
+        _lib.check(self.L.rm_frame_timing_enable(self.ptr, 1 if on else 0), self.ptr)
+
     def frame_timing(self, slot=0):
         t = _lib.rm_frame_times()
         _lib.check(self.L.rm_frame_timing(self.ptr, slot, C.byref(t)), self.ptr)

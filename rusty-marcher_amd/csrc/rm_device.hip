@@ -105,6 +105,7 @@ struct rm_frame_slot {
     hipEvent_t begun = nullptr, rendered = nullptr, gathered = nullptr;   // stamps of the frame on the slot's stream
     hipEvent_t exchanged = nullptr;   // recorded after the last operation of the slot's frame
     bool used = false;
+    bool stamped = false;             // the slot's last frame carries the stamps of rm_frame_timing
 };
 
 struct rm_ctx {
@@ -149,6 +150,7 @@ struct rm_ctx {
     void *comm = nullptr;             // ncclComm_t
     void *slot_comm[RM_MAX_FRAME_SLOTS] = {};   // per frame slot: `comm` itself, or (RM_SLOT_COMMS=1) one split off it
     int n_comms = 0;                  // distinct communicators in use
+    bool frame_stamps = false;        // rm_frame_timing_enable
     bool comm_failed = false;         // a frame wait timed out: the communicator is abandoned, not destroyed
     bool comm_local = false;          // rank/world set without a transport (rm_comm_init with id == NULL)
     int rank = 0, world = 1;

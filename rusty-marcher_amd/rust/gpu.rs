@@ -160,6 +160,7 @@ extern "C" {
     fn rm_frame_wait(ctx: *mut RmCtx, slot: u32) -> c_int;
     fn rm_frame_wait_for(ctx: *mut RmCtx, slot: u32, timeout_ms: u32) -> c_int;
     fn rm_frame_submit_f64(ctx: *mut RmCtx, params: *const RmParams, device_gather64: *mut c_void, device_frame64: *mut c_void, slot: u32) -> c_int;
+    fn rm_frame_timing_enable(ctx: *mut RmCtx, on: c_int) -> c_int;
     fn rm_frame_timing(ctx: *mut RmCtx, slot: u32, out: *mut RmFrameTimes) -> c_int;
     fn rm_comm_info(ctx: *mut RmCtx, rank: *mut c_int, world: *mut c_int, n_communicators: *mut c_int) -> c_int;
     fn rm_abi_version() -> u32;

@@ -783,6 +783,7 @@ def test_frame_submit_f64_layout_of_n_ranks_on_one_gpu(pkg, world):
     rows, chunk = cx.exchange_layout(p, world)
     gathered = torch.full((world * chunk,), -3., dtype=torch.float64, device="cuda:0")
     frame = torch.full((n_rows * 32, w, 3), -5., dtype=torch.float64, device="cuda:0")
+    cx.frame_timing_enable(True)
     for r in range(world):
         cx.comm_init(r, world)
         last = r == world - 1
