@@ -12,14 +12,15 @@ reference's FrameBuffer) and its display bytes (`to_vec`, what the UI blits) to 
 (the scene) are uploaded before the timed region.
 
 N > 1: the frame is sharded by 32-row patch rows (cyclic ownership: rank r
-renders patch rows r, r+N, ...) and ONE in-place RCCL all-gather per frame, inside the timed
-region, completes the display frame on every rank (--payload u8, the default; rank 0 is the
-consumer) or the f64 frame itself (--payload f64).  Two exchanges are measured, in this
-order, K steps each:
-  1. torch.distributed.all_gather_into_tensor per frame (two frames in flight) -- its
-     numbers are kept whatever happens next;
+renders patch rows r, r+N, ...) and ONE exchange per frame, inside the timed region, completes
+the display frame (--payload u8, the default) or the f64 frame itself (--payload f64) at the
+consumer, rank 0: every peer sends its rows straight to rank 0, all at once, each over its own
+xGMI link (--exchange gather, the default; --exchange allgather: one in-place all-gather, the
+frame on every rank).  Two implementations are measured, in this order, K steps each:
+  1. torch.distributed per frame (batch_isend_irecv / all_gather_into_tensor, two frames in
+     flight) -- its numbers are kept whatever happens next;
   2. the library's own exchange (rm_frame_submit / rm_frame_submit_f64: four frames in
-     flight, each on a stream of its own, ncclAllGather issued from C), first checked byte for
+     flight, each on a stream of its own, RCCL called from C), first checked byte for
      byte against (1), every wait bounded (RM_ERR_TIMEOUT, never a hang).
 `value` is the faster of the two when (2) completed and agreed, else (1)'s; the line says
 which and carries both.  Total work is fixed: "strong" scaling.
@@ -62,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--collective", choices=["direct", "torch"], default="direct",
                     help="N > 1: 'direct' = measure the torch all-gather path, then the library's own frame exchange "
                          "(rm_frame_submit*) and report the latter when it completes and agrees; 'torch' = the torch path only")
+    ap.add_argument("--exchange", choices=["gather", "allgather"], default="gather",
+                    help="N > 1: 'gather' = every peer sends its chunk straight to rank 0, the consumer (grouped send / recv: "
+                         "each over its own xGMI link); 'allgather' = one in-place all-gather, the frame on every rank")
     ap.add_argument("--fast-fp", action="store_true",
                     help="RM_FLAG_FAST_FP flavour of the kernel (FMA, Newton rsqrt): faster, but may decide "
                          "exact-incidence pixels differently from the reference -- not the parity configuration")
@@ -360,6 +364,7 @@ def rank_main(args):
         if ids[0] is not None:
             try:
                 ctx.comm_init(rank, world, ids[0])
+                ctx.comm_exchange(args.exchange == "allgather")
                 ok = 1 if ctx.comm_info()[:2] == (rank, world) else 0
             except Exception as e:                     # noqa: BLE001
                 sys.stderr.write("rank %d: rm_comm_init failed: %s\n" % (rank, e))
@@ -450,7 +455,8 @@ def rank_main(args):
             b = counter[0] % n_buf_torch
             counter[0] += 1
             if pending[b] is not None:
-                pending[b].wait()                      # stream-ordered; the host does not block
+                for wk in pending[b]:
+                    wk.wait()                          # stream-ordered; the host does not block
                 pending[b] = None
                 if images:
                     workloads.deinterleave_rows(gathered[b], world, images[b])
@@ -459,15 +465,19 @@ def rank_main(args):
                     check(L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[b], chunk_ptrs[b], stream_ptr))
                 else:
                     check(L.rm_render_device(ctx.ptr, p_ref, chunk_ptrs[b], stream_ptr))
-            pending[b] = dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)
+            if args.exchange == "allgather":
+                pending[b] = [dist.all_gather_into_tensor(gathered[b], my_chunk[b], async_op=True)]
+            else:
+                pending[b] = workloads.gather_chunks(dist, gathered[b], rank, world)
 
         def drain(direct):
             if direct:
                 for b in range(n_buf):
                     ctx.frame_wait(b)                   # bounded: raises RM_ERR_TIMEOUT
-            for i, wk in enumerate(pending):
-                if wk is not None:
-                    wk.wait()
+            for i, wks in enumerate(pending):
+                if wks is not None:
+                    for wk in wks:
+                        wk.wait()
                     pending[i] = None
                     if images:
                         workloads.deinterleave_rows(gathered[i], world, images[i])
@@ -534,7 +544,10 @@ def rank_main(args):
                     counter[0] = 0
                     step_direct()
                     fence(True)
-                    same = torch.equal(gathered[0], want) and (want_img is None or torch.equal(images[0], want_img))
+                    # (gathered at rank 0: a peer holds only its own chunk, in both paths)
+                    same = ((rank != 0 and args.exchange == "gather") or torch.equal(gathered[0], want)) and \
+                           torch.equal(my_chunk[0], want[rank * c_rows * 32:(rank + 1) * c_rows * 32]) and \
+                           (want_img is None or torch.equal(images[0], want_img))
                     flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                     if int(flag.item()) != 1:
@@ -679,8 +692,10 @@ def rank_main(args):
             except Exception as e:                      # noqa: BLE001
                 pmc_note = "profiles/pmc_latest.json unreadable: %s" % e
         coll = {"none": "none (one GPU)",
-                "direct": "rm_frame_submit%s: ncclAllGather from the C library" % ("_f64" if args.payload == "f64" else ""),
-                "torch": "torch.distributed.all_gather_into_tensor (%s)" % ("RCCL" if backend == "nccl" else backend)}[chosen]
+                "direct": "rm_frame_submit%s: %s from the C library" % ("_f64" if args.payload == "f64" else "",
+                                                                       "ncclAllGather" if args.exchange == "allgather" else "grouped ncclSend / ncclRecv to rank 0"),
+                "torch": "torch.distributed %s (%s)" % ("all_gather_into_tensor" if args.exchange == "allgather" else "batch_isend_irecv to rank 0",
+                                                       "RCCL" if backend == "nccl" else backend)}[chosen]
         note = note or state["direct_note"]
         out = {
             "metric": "Mpixels/sec at 1920x1080, max-bounce=5" if args.config == "C2"
@@ -691,9 +706,11 @@ def rank_main(args):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s scene %dx%d, depth cap %d, fov 1.5, device-resident f64 RGB frame"
                                    % (args.config, cfg["scene"], w, h, depth),
-                       "sharding": ("cyclic patch rows (rank r: rows r, r+N, ...), %d of 32 px per rank, %d rank(s), one in-place "
-                                    "RCCL all-gather of the %s rows per frame%s"
-                                    % (c_rows, world, args.payload, "" if args.payload == "f64" else "; f64 rows stay in each rank's HBM"))
+                       "sharding": ("cyclic patch rows (rank r: rows r, r+N, ...), %d of 32 px per rank, %d rank(s), %s of the %s rows "
+                                    "per frame%s"
+                                    % (c_rows, world, "one in-place RCCL all-gather" if args.exchange == "allgather" else
+                                       "one gather at rank 0 (grouped send / recv, every peer over its own link)",
+                                       args.payload, "" if args.payload == "f64" else "; f64 rows stay in each rank's HBM"))
                                    if cyclic else "one GPU renders all %d patch rows" % c_rows,
                        "collective": coll + (" [%s]" % note if note else ""),
                        "frames_in_flight": best.get("frames_in_flight", 1),

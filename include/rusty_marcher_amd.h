@@ -293,9 +293,11 @@ void rm_host_free(rm_ctx *ctx, void *host_ptr);
  * Replaces, for N GPUs, what renderer.rs:63-108 does with N Rayon workers: the patch rows
  * of a frame are owned cyclically (rank r renders patch rows r, r+N, r+2N, ... so that
  * every rank gets its share of cheap sky and expensive ground rows), each rank's f64 rows
- * stay in its own `device_rgb` (a distributed FrameBuffer), and ONE in-place RCCL
- * all-gather per frame completes the display frame (`to_vec` bytes, framebuffer.rs:40-55)
- * on every rank.  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream of its
+ * stay in its own `device_rgb` (a distributed FrameBuffer), and ONE RCCL exchange per frame
+ * completes the display frame (`to_vec` bytes, framebuffer.rs:40-55) at the consumer, RANK 0
+ * (the reference has one window, main.rs:337-346): every peer sends its chunk straight to rank 0
+ * over its own xGMI link, all at once (grouped ncclSend / ncclRecv).  rm_comm_exchange(ctx, 1)
+ * on every rank selects an in-place ncclAllGather instead (the frame on every rank).  Up to RM_MAX_FRAME_SLOTS frames are in flight; a slot has a stream of its
  * own (render, gather, de-interleave in order on the stream); every rank must submit the
  * same sequence of (frame, slot) pairs.  All slots share ONE communicator unless
  * RM_SLOT_COMMS=1 is exported on EVERY rank (then each slot gets one split off the first;
@@ -311,6 +313,9 @@ void rm_host_free(rm_ctx *ctx, void *host_ptr);
 rm_status rm_comm_unique_id(void *id_out /* RM_COMM_ID_BYTES */);
 rm_status rm_comm_init(rm_ctx *ctx, const void *id, int rank, int world);
 void rm_comm_destroy(rm_ctx *ctx);   /* also done by rm_destroy */
+/* all_ranks = 0 (default): the chunks are gathered at rank 0; 1: all-gathered, every rank ends
+ * up with the whole gather buffer.  The same on every rank, before the first submit. */
+rm_status rm_comm_exchange(rm_ctx *ctx, int all_ranks);
 
 /* Layout of the gather buffer for `world` ranks: world chunks of rows_per_rank patch rows
  * (32 * frame_width * 3 bytes each); chunk k holds patch rows k, k+world, ... packed. */
@@ -319,9 +324,10 @@ rm_status rm_exchange_layout(const rm_params *params, int world, uint32_t *rows_
 /*
  * One frame, asynchronously: renders this rank's rows into device_rgb ([H][W][3] f64,
  * only the owned rows are written) and their display bytes into this rank's chunk of
- * device_gather8 (world * chunk_bytes), all-gathers the chunks in place, and -- where
- * device_display8 is not NULL (the consumer, e.g. rank 0's window) -- writes the
- * [32*n_patch_rows][W][3] image-order display frame.  params->patch_row_* must be zero.
+ * device_gather8 (world * chunk_bytes), gathers the chunks there (at rank 0; with
+ * rm_comm_exchange(ctx, 1) on every rank), and -- where device_display8 is not NULL (the
+ * consumer: rank 0) -- writes the [32*n_patch_rows][W][3] image-order display frame.
+ * params->patch_row_* must be zero.
  * All four buffers belong to `slot` until rm_frame_wait(slot) returns or the slot is
  * submitted again (a slot's frames are ordered); two slots must not share a buffer.
  */
@@ -343,8 +349,9 @@ rm_status rm_frame_wait_for(rm_ctx *ctx, uint32_t slot, uint32_t timeout_ms);
 /*
  * The f64 frame itself (framebuffer.rs:6-22: the reference's render target is f64) to the
  * consumer: this rank's rows are rendered packed (RM_FLAG_F64_COMPACT) straight into its
- * chunk of device_gather64 (world * 8 * chunk_bytes of rm_exchange_layout), ONE in-place
- * all-gather completes the buffer on every rank, and -- where device_frame64 is not NULL --
+ * chunk of device_gather64 (world * 8 * chunk_bytes of rm_exchange_layout), ONE exchange
+ * completes the buffer at rank 0 (on every rank with rm_comm_exchange(ctx, 1)), and -- where
+ * device_frame64 is not NULL --
  * the [32*n_patch_rows][W][3] f64 frame is written in image order, bit-identical to the
  * single-GPU frame.  8x the bytes of the display path: at 1080p ~6 MB per peer per frame.
  * Frames in flight (slots) overlap one frame's gather with the next frame's render.

@@ -123,6 +123,7 @@ SIGNATURES = {
     "rm_comm_unique_id": (C.c_int, [_VP]),
     "rm_comm_init": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "rm_comm_destroy": (None, [_VP]),
+    "rm_comm_exchange": (C.c_int, [_VP, C.c_int]),
     "rm_exchange_layout": (C.c_int, [_P(rm_params), C.c_int, _P(C.c_uint32), _P(C.c_size_t)]),
     "rm_frame_submit": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP, C.c_uint32]),
     "rm_frame_wait": (C.c_int, [_VP, C.c_uint32]),

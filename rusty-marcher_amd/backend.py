@@ -68,6 +68,10 @@ class Context:
             raise ValueError("unique_id must be %d bytes" % _lib.RM_COMM_ID_BYTES)
         _lib.check(self.L.rm_comm_init(self.ptr, unique_id, rank, world), self.ptr)
 
+    def comm_exchange(self, all_ranks):
+        """False (default): chunks gathered at rank 0; True: all-gathered on every rank."""
+        _lib.check(self.L.rm_comm_exchange(self.ptr, 1 if all_ranks else 0), self.ptr)
+
     def comm_destroy(self):
         self.L.rm_comm_destroy(self.ptr)
 

@@ -151,6 +151,7 @@ struct rm_ctx {
     void *slot_comm[RM_MAX_FRAME_SLOTS] = {};   // per frame slot: `comm` itself, or (RM_SLOT_COMMS=1) one split off it
     int n_comms = 0;                  // distinct communicators in use
     bool frame_stamps = false;        // rm_frame_timing_enable
+    bool exchange_all_ranks = false;  // rm_comm_exchange: all-gather instead of the gather at rank 0
     bool comm_failed = false;         // a frame wait timed out: the communicator is abandoned, not destroyed
     bool comm_local = false;          // rank/world set without a transport (rm_comm_init with id == NULL)
     int rank = 0, world = 1;

@@ -154,6 +154,7 @@ extern "C" {
     fn rm_comm_unique_id(id_out: *mut c_void) -> c_int; // 128 bytes
     fn rm_comm_init(ctx: *mut RmCtx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
     fn rm_comm_destroy(ctx: *mut RmCtx);
+    fn rm_comm_exchange(ctx: *mut RmCtx, all_ranks: c_int) -> c_int;
     fn rm_exchange_layout(params: *const RmParams, world: c_int, rows_per_rank: *mut u32, chunk_bytes: *mut usize) -> c_int;
     fn rm_frame_submit(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, slot: u32) -> c_int;
     fn rm_frame_submit_to_host(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_gather8: *mut c_void, device_display8: *mut c_void, host_display8: *mut c_void, slot: u32) -> c_int;

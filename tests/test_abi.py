@@ -131,4 +131,5 @@ def test_exchange_layout_and_comm_entry_points_without_a_gpu(pkg):
     assert L.rm_frame_timing(None, 0, None) == E
     assert L.rm_frame_timing_enable(None, 1) == E
     assert L.rm_comm_info(None, None, None, None) == E
+    assert L.rm_comm_exchange(None, 1) == E
     assert L.rm_buffer_write(None, None, None, 0) == E

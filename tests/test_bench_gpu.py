@@ -44,7 +44,11 @@ def test_one_gpu_line_has_the_contract_fields():
 def test_two_ranks_self_spawned_on_this_gpu_over_gloo():
     d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--check", "--no-sizes"], env={"RM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["display_bytes_differing_from_oracle"] == 0
-    assert "cyclic patch rows" in d["config"]["sharding"] and "torch" in d["exchange_paths"]
+    assert "cyclic patch rows" in d["config"]["sharding"] and "gather at rank 0" in d["config"]["sharding"]
+    assert "torch" in d["exchange_paths"]
+    d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--check", "--no-sizes", "--exchange", "allgather"],
+               env={"RM_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["display_bytes_differing_from_oracle"] == 0 and "all-gather" in d["config"]["sharding"]
     d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--check", "--no-sizes", "--payload", "f64"],
                env={"RM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["max_abs_delta_vs_oracle"] < 1e-9

@@ -172,3 +172,42 @@ def test_cyclic_rows_allgather_and_deinterleave(O, tmp_path, world, w, h):
     n_rows = h // 32
     ref = O.render(O.OracleScene.create_default(), w, h, max_depth=3)
     assert np.array_equal(got[:n_rows * 32].reshape(-1), O.to_vec(ref[:n_rows * 32].copy()))
+
+
+def _worker_gather_chunks(rank, world, port, w, h, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    import workloads
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        O = G.load_oracle()
+        n_rows = h // 32
+        c, owned = workloads.cyclic_rows(n_rows, world)
+        full = np.zeros((h, w, 3))
+        O.render(O.OracleScene.create_default(), w, h, max_depth=3, n_threads=2, frame=full)
+        u8 = torch.from_numpy(O.to_vec(full[:n_rows * 32].copy()).reshape(n_rows * 32, w, 3))
+        gathered = torch.full((world * c * 32, w, 3), 7, dtype=torch.uint8)
+        for j, prow in enumerate(owned[rank]):                       # this rank's rows, packed into its chunk
+            gathered[(rank * c + j) * 32:(rank * c + j + 1) * 32] = u8[prow * 32:(prow + 1) * 32]
+        for req in workloads.gather_chunks(dist, gathered, rank, world):
+            req.wait()
+        dist.barrier()
+        if rank == 0:
+            image = workloads.deinterleave_rows(gathered, world, torch.zeros_like(gathered))
+            np.save(out_path, np.stack([image[:n_rows * 32].numpy(), u8.numpy()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 64, 100), (3, 96, 224), (4, 64, 40)])
+def test_chunks_gathered_at_rank_0_reassemble_the_display_frame(tmp_path, world, w, h):
+    """bench.py's default N > 1 exchange (workloads.gather_chunks: every peer sends its packed
+    cyclic rows straight to rank 0, one grouped isend / irecv) + the de-interleave at the
+    consumer: rank 0 ends up with the display frame in image order."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker_gather_chunks, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    got, want = np.load(out)
+    assert np.array_equal(got, want)

@@ -181,6 +181,22 @@ def allgather_bands(dist, padded, rank, world):
     dist.all_gather_into_tensor(padded, padded[rank * rows:(rank + 1) * rows])
 
 
+def gather_chunks(dist, gathered, rank, world, dst=0):
+    """The one exchange of a cyclically sharded frame with ONE consumer: `gathered` is the
+    [world * c * 32, W, 3] buffer of rank-major chunks in which this rank has filled its own chunk;
+    every peer sends that chunk straight to rank `dst` (grouped isend / irecv: on GPUs each peer
+    over its own xGMI link, all at once).  Returns the requests (wait() orders the stream)."""
+    rows = gathered.shape[0] // world
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            if r != dst:
+                ops.append(dist.P2POp(dist.irecv, gathered[r * rows:(r + 1) * rows], r))
+    else:
+        ops.append(dist.P2POp(dist.isend, gathered[rank * rows:(rank + 1) * rows], dst))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 def cyclic_rows(n_patch_rows, world):
     """Cyclic ownership for load balance (sky rows are cheap, ground rows
     expensive): rank r owns patch rows r, r + N, r + 2N, ... -- rm_params band
