@@ -136,7 +136,7 @@ struct rm_ctx {
     // Ray bundles whose half-angle has at least this cosine cull primitives before a walk
     // (rm_trace.inc); wider ones take the plain walk / the hierarchy.  RM_DISABLE_CULL=1 sets 2
     // (never), RM_CULL_COS overrides (A/B knobs).
-    double cull_cos = 0.9;
+    double cull_cos = 0.975;          // (synthetic-256: 0.9 1,911 us, 0.95 1,825, 0.97-0.98 1,777, 0.99 1,791, 0.999 1,847; cornell flat)
     uint32_t cull_min_prims = RM_CULL_MIN_PRIMS;   // RM_CULL_MIN (A/B knob)
     bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
@@ -257,7 +257,8 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
     if (const char *env = std::getenv("RM_DISABLE_CULL")) ctx->cull_cos = env[0] == '1' ? 2. : ctx->cull_cos;
-    if (const char *env = std::getenv("RM_CULL_COS")) ctx->cull_cos = std::atof(env);
+    if (const char *env = std::getenv("RM_CULL_COS"))   // (the cone tests hold for half-angles below 90 degrees)
+        ctx->cull_cos = std::max(0.05, std::atof(env));
     if (const char *env = std::getenv("RM_CULL_MIN")) ctx->cull_min_prims = (uint32_t)std::strtoul(env, nullptr, 10);
     *out = ctx;
     return RM_OK;
