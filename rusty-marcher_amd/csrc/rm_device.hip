@@ -158,6 +158,11 @@ struct rm_ctx {
     int rank = 0, world = 1;
     rm_frame_slot slots[RM_MAX_FRAME_SLOTS];
 
+    // backproject tables (per column, per row) of the current frame geometry
+    double *d_backproject = nullptr;
+    size_t backproject_words = 0;
+    double backproject_key[6] = {};
+
     // post-process scratch
     unsigned long long *d_max = nullptr;
     uint8_t *d_rgb8 = nullptr;
@@ -278,6 +283,7 @@ void rm_destroy(rm_ctx *ctx) {
     }
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_backproject) (void)hipFree(ctx->d_backproject);
     if (ctx->d_max) (void)hipFree(ctx->d_max);
     if (ctx->d_rgb8) (void)hipFree(ctx->d_rgb8);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -634,6 +640,28 @@ static rm_status check_params(rm_ctx *ctx, const rm_params *p, rm_band *band) {
     return RM_OK;
 }
 
+// backproject (renderer.rs:128-135): `2 (x / width - 0.5) half_fov ratio` per column and
+// `-2 (y / height - 0.5) half_fov` per row, tabulated with the operations the kernel used to
+// perform per pixel, in their order (this file is compiled with -ffp-contract=off): the same
+// IEEE results.  Rebuilt when the Renderer or the frame geometry changes.
+static rm_status backproject_tables(rm_ctx *ctx, const rm_params *p) {
+    const double key[6] = {p->width, p->height, p->half_fov, p->ratio, (double)p->frame_width, (double)p->frame_height};
+    if (ctx->d_backproject && std::memcmp(key, ctx->backproject_key, sizeof key) == 0) return RM_OK;
+    std::vector<double> t((size_t)p->frame_width + p->frame_height);
+    for (uint32_t x = 0; x < p->frame_width; x++) t[x] = 2. * ((double)x / p->width - 0.5) * p->half_fov * p->ratio;
+    for (uint32_t y = 0; y < p->frame_height; y++) t[p->frame_width + y] = -2. * ((double)y / p->height - 0.5) * p->half_fov;
+    RM_HIP(ctx, hipDeviceSynchronize());                       // a launch in flight may still read the old tables
+    if (ctx->backproject_words < t.size()) {
+        if (ctx->d_backproject) RM_HIP(ctx, hipFree(ctx->d_backproject));
+        ctx->d_backproject = nullptr;
+        RM_HIP(ctx, hipMalloc(&ctx->d_backproject, t.size() * sizeof(double)));
+        ctx->backproject_words = t.size();
+    }
+    RM_HIP(ctx, hipMemcpy(ctx->d_backproject, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::memcpy(ctx->backproject_key, key, sizeof key);
+    return RM_OK;
+}
+
 // Which kernel instantiation a render with these params launches, and how.
 struct rm_kernel_choice {
     const void *fn = nullptr;
@@ -690,8 +718,12 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         }
         return RM_OK;
     }
+    rm_status bst = backproject_tables(ctx, p);
+    if (bst != RM_OK) return bst;
     KernelArgs a{};
     a.H = ctx->H;
+    a.bp_x = ctx->d_backproject;
+    a.bp_y = ctx->d_backproject + p->frame_width;
     a.half_fov = p->half_fov; a.height = p->height; a.width = p->width; a.ratio = p->ratio;
     a.cam_x = ctx->camera.x; a.cam_y = ctx->camera.y; a.cam_z = ctx->camera.z;
     a.bg_x = p->background.x; a.bg_y = p->background.y; a.bg_z = p->background.z;

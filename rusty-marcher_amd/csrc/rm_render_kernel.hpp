@@ -58,6 +58,9 @@ struct KernelArgs {
     uint32_t f64_compact;                    // RM_FLAG_F64_COMPACT: frame holds only the owned rows, packed
     double cull_cos;                         // bundles at least this narrow cull primitives (> 1: never; RM_DISABLE_CULL)
     uint8_t *frame8;                         // optional [H][W][3] u8 display frame (NULL: not written)
+    // backproject (renderer.rs:128-135) tabulated per column and per row by the host with the
+    // kernel's own operations: bp_x[x] = 2 (x / width - 0.5) half_fov ratio, bp_y[y] = -2 (y / height - 0.5) half_fov
+    const double *bp_x, *bp_y;
     unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
 };
 
