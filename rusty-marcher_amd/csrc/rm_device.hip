@@ -217,7 +217,7 @@ static const void *pick_kernel(int stack, int pow_mode, bool fast) {
 extern "C" {
 
 const char *rm_build_info(void) {
-    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi1";
+    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi2";
 }
 
 const char *rm_last_error(const rm_ctx *ctx) {
