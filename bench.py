@@ -185,13 +185,18 @@ def cpu_model():
 
 
 def csrc_hash():
-    """sha256 over the kernel sources: ties profiles/pmc_latest.json to a build."""
+    """sha256 over the kernel sources (comments and white space apart): ties
+    profiles/pmc_latest.json to a build."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rusty-marcher_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".inc", ".hpp", ".h", ".cpp")):
+            text = open(os.path.join(d, name), errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
