@@ -89,10 +89,11 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
 // This build instantiates one tile per wave only (1 wave per workgroup with the LDS scene
 // copy, 4 without); the other geometries were measured with earlier builds.
-static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4, RM_CULL_MAX_PRIMS = 2048;
+static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4, RM_CULL_MAX_COST = 250;
+static inline uint32_t k_planar_from(const rm_dev_header &H) { return H.n_spheres; }   // pid of the first planar primitive
 
 struct rm_launch_mode {
-    int waves = 0;      // waves per workgroup; 0 = choose from the scene size at launch
+    int waves = 0;      // waves per workgroup
     int per_wave = 1;   // tiles per wave
 };
 
@@ -110,7 +111,6 @@ struct rm_frame_slot {
 
 struct rm_ctx {
     int device = -1;
-    rm_launch_mode mode;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string error;
@@ -737,10 +737,18 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     a.n_tiles = n_rows * n_width * 16u;
     a.debug_stamps = nullptr;
     a.frame8 = d_frame8;
-    // a cull step handles 64 primitives: beyond a few thousand the hierarchy walk is the
-    // cheaper way to find the few a bundle can reach (2 = no bundle is ever narrow enough)
+    // A cull step handles 64 primitives for ~25 vector instructions, ~110 when it holds planar
+    // primitives and the edge test runs; a bundle pays for every step.  The hierarchy walk finds a
+    // bundle's few primitives in a few hundred instructions whatever their number, so scenes whose
+    // cull would cost more than that take the hierarchy only (2 = no bundle is ever narrow
+    // enough).  Measured at 1080p: 36 triangles cull 67 us / hierarchy 110; 320 triangles
+    // 190 / 119; 1,280 triangles 389 / 155; 256 spheres + 1 quad 1.76 ms / 2.77.
     const uint32_t n_prims_all = ctx->H.n_spheres + ctx->H.n_polygons + ctx->H.n_triangles;
-    a.cull_cos = n_prims_all > RM_CULL_MAX_PRIMS ? 2. : ctx->cull_cos;
+    const uint32_t cull_steps = (n_prims_all + 63u) / 64u;
+    const uint32_t planar_steps = (k_planar_from(ctx->H) < n_prims_all) ? cull_steps - k_planar_from(ctx->H) / 64u : 0u;
+    const bool edges_on = ctx->H.n_polygons + ctx->H.n_triangles >= RM_CULL_EDGES_MIN_PLANAR;
+    const uint32_t cull_cost = 25u * cull_steps + (edges_on ? 85u * planar_steps : 0u);
+    a.cull_cos = cull_cost > RM_CULL_MAX_COST ? 2. : ctx->cull_cos;
     // dispatch order: tile = (id * order_mul + order_add) % n_tiles, a bijection
     a.order_mul = 1; a.order_add = 0;
     if (ctx->tile_order == TILE_ORDER_REVERSE && a.n_tiles > 1) {             // id -> n-1-id
