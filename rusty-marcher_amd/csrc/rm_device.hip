@@ -140,6 +140,7 @@ struct rm_ctx {
     double cull_cos = 0.975;          // (synthetic-256: 0.9 1,911 us, 0.95 1,825, 0.97-0.98 1,777, 0.99 1,791, 0.999 1,847; cornell flat)
     uint32_t cull_min_prims = RM_CULL_MIN_PRIMS;   // RM_CULL_MIN (A/B knob)
     bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
+    int force_stack = 0;              // RM_FORCE_STACK=4|8|16|32: a deeper ray stack than the depth cap needs (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
 
     // device framebuffer of rm_render
@@ -258,6 +259,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FORCE_FAST_FP")) ctx->force_fast_fp = env[0] == '1';
     if (const char *env = std::getenv("RM_FORCE_UNSTAGED")) ctx->force_unstaged = env[0] == '1';
     if (const char *env = std::getenv("RM_DISABLE_BVH")) ctx->disable_bvh = env[0] == '1';
+    if (const char *env = std::getenv("RM_FORCE_STACK")) ctx->force_stack = std::atoi(env);
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -672,8 +674,8 @@ struct rm_kernel_choice {
 };
 
 static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice *k) {
-    // launch geometry: one tile per wave; small scenes get one wave per workgroup and an LDS
-    // copy of the scene for the per-lane gathers, larger ones four waves and none
+    // launch geometry: one tile per wave, one wave per workgroup; small scenes get an LDS copy
+    // of the scene for the per-lane gathers, larger ones none
     const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
     const uint32_t n_prims = ctx->H.n_spheres + ctx->H.n_polygons + ctx->H.n_triangles;
     k->bvh = ctx->H.off_bvh_spheres != 0 || ctx->H.off_bvh_triangles != 0;
@@ -681,20 +683,25 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice
     // Bundle culling pays from about a dozen primitives on (a cull step costs about what two
     // primitive tests cost); the six primitives of the demo scene are walked as they are.
     k->cull = n_prims >= ctx->cull_min_prims || !k->staged;
-    k->mode.waves = k->staged ? 1 : 4;
+    // One wave per workgroup in every kernel: the waves of a workgroup share nothing but the LDS
+    // scene copy (which only small scenes get), and a wave slot a workgroup of four has freed is
+    // handed on only when the whole workgroup fits -- with tiles of 1 to 18 ray steps that kept
+    // 2.6 of a SIMD's 4 slots filled on the 256-sphere scene (1,777 -> 1,425 us with one wave).
+    k->mode.waves = 1;
     k->mode.per_wave = 1;
     k->lds_bytes = ((k->staged ? (size_t)ctx->H.total_words : 0u) + (size_t)k->mode.waves * RM_WAVE_LDS_WORDS) * sizeof(double);
 
     // A lane parks at most one sibling per level below the cap: max_depth - 1 entries.
     k->stack = p->max_depth <= 5 ? 4 : p->max_depth <= 9 ? 8 : p->max_depth <= 17 ? 16 : 32;
+    if (ctx->force_stack > k->stack && (ctx->force_stack == 8 || ctx->force_stack == 16 || ctx->force_stack == 32)) k->stack = ctx->force_stack;
     k->pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
     k->fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
     // the cull's edge test for planar primitives where there are several of them
     k->edges = k->cull && ctx->H.n_polygons + ctx->H.n_triangles >= RM_CULL_EDGES_MIN_PLANAR;
     const int st = k->stack, pw = k->pow_mode;
     const bool f = k->fast;
-    k->fn = !k->staged ? (k->bvh ? (k->edges ? pick_kernel<4, false, true, true, true>(st, pw, f) : pick_kernel<4, false, true, true, false>(st, pw, f))
-                                 : (k->edges ? pick_kernel<4, false, false, true, true>(st, pw, f) : pick_kernel<4, false, false, true, false>(st, pw, f)))
+    k->fn = !k->staged ? (k->bvh ? (k->edges ? pick_kernel<1, false, true, true, true>(st, pw, f) : pick_kernel<1, false, true, true, false>(st, pw, f))
+                                 : (k->edges ? pick_kernel<1, false, false, true, true>(st, pw, f) : pick_kernel<1, false, false, true, false>(st, pw, f)))
           : k->cull    ? (k->edges ? pick_kernel<1, true, false, true, true>(st, pw, f) : pick_kernel<1, true, false, true, false>(st, pw, f))
                        : pick_kernel<1, true, false, false, false>(st, pw, f);
     return RM_OK;
