@@ -426,7 +426,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     // 32-bit word offsets: refuse scenes they cannot address
     const uint64_t need_words = (uint64_t)H.n_spheres * RM_SPHERE_WORDS + (uint64_t)H.n_polygons * RM_POLYGON_WORDS +
                                 ((uint64_t)n_pverts + 1u) * RM_PVERT_WORDS + (uint64_t)H.n_triangles * RM_TRIANGLE_WORDS +
-                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u + 4u + 16u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
+                                (uint64_t)n_prims * (RM_MATERIAL_WORDS + 1u + 4u + 16u + 1u) + (uint64_t)H.n_lights * RM_LIGHT_WORDS +
                                 bvh_s.nodes.size() + bvh_t.nodes.size() + 256u;
     if (need_words > RM_SCENE_MAX_WORDS)
         return ctx_fail(ctx, RM_ERR_SCENE_LIMIT, "rm_scene_upload: scene exceeds the 32 GiB the device layout can address");
@@ -441,6 +441,8 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     H.off_keys = take((n_prims + 1u) / 2u);
     H.off_bounds = take(n_prims * 4u);
     H.off_planar = take((H.n_polygons + H.n_triangles) * 16u);
+    const uint32_t n_groups = (n_prims + 63u) / 64u;
+    H.off_groups = (n_groups >= 3u && n_groups <= 64u) ? take(n_groups * 4u) : 0u;
     // The wave's hierarchy stack holds 64 entries, one parked sibling per level: the builder
     // keeps every tree under RM_BVH_MAX_DEPTH levels (rm_bvh.hpp); a tree that is deeper all
     // the same is not walked (its primitives keep their leaf order and are walked flat).
@@ -555,6 +557,37 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         for (int v = 0; v < 3; v++) { w[6 + 2 * v] = t.vertices[v].x; w[7 + 2 * v] = t.vertices[v].y; }
         put_material(pid, t.reflectance);
         planar_bounds(pid, t.normal, t.center, t.vertices, 3u);
+    }
+    // The cull's first step in scenes of 3+ steps: a sphere around the bounding spheres of each 64
+    // consecutive pids (box centre of the members; primitives that can never be hit -- radius -1 --
+    // do not count, a group of nothing else is never visited).
+    for (uint32_t g = 0; H.off_groups && g < n_groups; g++) {
+        const uint32_t first = g * 64u, last = std::min(n_prims, first + 64u);
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        bool any = false, unbounded = false;
+        for (uint32_t q = first; q < last; q++) {
+            const double *w = &blob[H.off_bounds + 4u * q];
+            if (w[3] < 0.) continue;
+            any = true;
+            if (!std::isfinite(w[3])) { unbounded = true; continue; }
+            for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], w[c] - w[3]); hi[c] = std::max(hi[c], w[c] + w[3]); }
+        }
+        double *o = &blob[H.off_groups + 4u * g];
+        if (!any) { o[0] = o[1] = o[2] = 0.; o[3] = -1.; continue; }
+        if (unbounded) { o[0] = o[1] = o[2] = 0.; o[3] = std::numeric_limits<double>::infinity(); continue; }
+        const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+        double r = 0.;
+        for (uint32_t q = first; q < last; q++) {
+            const double *w = &blob[H.off_bounds + 4u * q];
+            if (w[3] < 0.) continue;
+            const double dx = w[0] - cx, dy = w[1] - cy, dz = w[2] - cz;
+            r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) + w[3]);
+        }
+        const double mag = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);
+        double rr = r * (1. + 1e-9) + 1e-12 * (1. + mag);
+        if (!std::isfinite(rr) || !std::isfinite(mag)) { o[0] = o[1] = o[2] = 0.; rr = std::numeric_limits<double>::infinity(); }
+        else { o[0] = cx; o[1] = cy; o[2] = cz; }
+        o[3] = rr;
     }
     // renderer.rs:168-172: a shadow ray starts 1e-3 of the normal off the hit point and runs
     // along normalize(light - point): it passes within 1e-3 |normal| of the light

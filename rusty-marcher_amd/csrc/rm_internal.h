@@ -34,6 +34,8 @@ const char *rm_get_host_error();
 //   planar    16 words per polygon / triangle: up to four vertices lifted onto the plane of the
 //                               hit test (a triangle repeats its first), the vertex count
 //                               (0: no edge test -- more than four vertices, or no finite lift)
+//   groups    4 words per 64 consecutive pids: a sphere around their bounding spheres (the
+//                               cull's first step)
 //   bvh       16 words per node (rm_bvh.hpp), one hierarchy over the spheres and one
 //                               over the triangles when there are enough of them; the
 //                               primitives of a kind are then stored in leaf order
@@ -46,7 +48,7 @@ struct rm_dev_header {
     uint32_t off_bvh_triangles;   // 0 = walk all triangles; else the triangle hierarchy
     uint32_t off_bounds;          // bounding sphere per pid (centre, radius: 4 words), inflated -- the bundle cull reads these
     uint32_t off_planar;          // per polygon / triangle (pid - n_spheres): lifted vertices + count, 16 words (cull_step)
-    uint32_t _pad;
+    uint32_t off_groups;          // 0, or (scenes of 3 to 64 cull steps) a bounding sphere per 64 consecutive pids, 4 words each
     double shadow_rho;            // every shadow ray passes within this of its light: 1e-3 x the longest normal (renderer.rs:168-172)
 };
 
