@@ -109,6 +109,31 @@ struct rm_frame_slot {
     bool stamped = false;             // the slot's last frame carries the stamps of rm_frame_timing
 };
 
+// Frame-to-frame feedback.  The cost of a tile is known only once it has been rendered -- 1 to
+// 18 ray steps on the 256-sphere scene, the incoherent ones thirty times the price of a coherent
+// one -- and a launch ends with whatever long tile was dispatched late: there the last 150 of
+// 260,000 waves ran for 200 of the launch's 1,600 us on an empty chip.  Frames of a render loop
+// resemble their predecessors, so every wave times its tile, the tiles that took long are put on
+// a list (one atomic each: they are few) and the next frame ON THE SAME STREAM dispatches the
+// list first.  Nothing is carried over but the order of dispatch: every tile of every frame is
+// rendered in full, by the same code.  Three rotating sets (list, count, one flag per tile): a
+// frame reads one, fills the next and clears the counter of the third.  Kept per stream --
+// launches on one stream are ordered, so a set is never read and written at once.
+struct rm_feedback {
+    hipStream_t stream = nullptr;
+    uint64_t key[3] = {0, 0, 0};      // launch geometry and scene the sets belong to
+    uint32_t n_tiles = 0, cap = 0;
+    void *block = nullptr;            // one allocation: 3 x (hist[64] | count | 3 pad | list[cap] u32 | flag[n_tiles] u8) + threshold
+    size_t set_bytes = 0;
+    int cur = 0;                      // the set the next frame reads
+    uint64_t used = 0;
+    uint32_t *hist(int j) const { return reinterpret_cast<uint32_t *>(static_cast<char *>(block) + (size_t)j * set_bytes); }
+    uint32_t *count(int j) const { return hist(j) + RM_FB_BUCKETS; }          // (cleared together with the histogram)
+    uint32_t *list(int j) const { return hist(j) + RM_FB_BUCKETS + 4u; }
+    uint8_t *flag(int j) const { return reinterpret_cast<uint8_t *>(list(j) + cap); }
+    uint32_t *threshold() const { return hist(3); }
+};
+
 struct rm_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -142,6 +167,13 @@ struct rm_ctx {
     bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
     int force_stack = 0;              // RM_FORCE_STACK=4|8|16|32: a deeper ray stack than the depth cap needs (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
+    // frame-to-frame feedback (rm_feedback): RM_FEEDBACK=0 never, 1 always, unset: launches of
+    // RM_FEEDBACK_MIN_TILES tiles and more with a depth cap of 6 and more (below, no tile is long)
+    int feedback_mode = -1;
+    uint32_t feedback_us = 50;        // RM_FEEDBACK_US: a tile is long from here on, until a frame's histogram says better
+    int feedback_target = -1;         // RM_FEEDBACK_TARGET: tiles the list should hold (-1: two per wave slot; 0: fixed threshold)
+    std::vector<rm_feedback> feedback;
+    uint64_t feedback_clock = 0, scene_epoch = 0;
 
     // device framebuffer of rm_render
     double *d_frame = nullptr;
@@ -260,6 +292,9 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FORCE_UNSTAGED")) ctx->force_unstaged = env[0] == '1';
     if (const char *env = std::getenv("RM_DISABLE_BVH")) ctx->disable_bvh = env[0] == '1';
     if (const char *env = std::getenv("RM_FORCE_STACK")) ctx->force_stack = std::atoi(env);
+    if (const char *env = std::getenv("RM_FEEDBACK")) ctx->feedback_mode = env[0] == '1' ? 1 : 0;
+    if (const char *env = std::getenv("RM_FEEDBACK_US")) ctx->feedback_us = (uint32_t)std::max(1, std::atoi(env));
+    if (const char *env = std::getenv("RM_FEEDBACK_TARGET")) ctx->feedback_target = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -283,6 +318,8 @@ void rm_destroy(rm_ctx *ctx) {
         for (hipEvent_t e : {s.begun, s.rendered, s.gathered, s.exchanged})
             if (e) (void)hipEventDestroy(e);
     }
+    for (rm_feedback &f : ctx->feedback)
+        if (f.block) (void)hipFree(f.block);
     if (ctx->d_scene) (void)hipFree(ctx->d_scene);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_backproject) (void)hipFree(ctx->d_backproject);
@@ -622,6 +659,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     ctx->H = H;
     ctx->camera = d->camera;
     ctx->have_scene = true;
+    ctx->scene_epoch++;                                      // (the feedback of another scene's frames is void)
     // specular_pow<POW_INTEGER> applies when pow(x, y) is a plain integer power for every material
     bool int_exp = true;
     for (uint32_t q = 0; q < n_prims; q++) {
@@ -694,6 +732,44 @@ static rm_status backproject_tables(rm_ctx *ctx, const rm_params *p) {
     }
     RM_HIP(ctx, hipMemcpy(ctx->d_backproject, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
     std::memcpy(ctx->backproject_key, key, sizeof key);
+    return RM_OK;
+}
+
+static constexpr uint32_t RM_FEEDBACK_MIN_TILES = 32768, RM_FEEDBACK_STREAMS = 8;
+
+// The feedback sets of launches of this geometry on this stream (created, or cleared when the
+// geometry or the scene changed: the first frame then has no list).
+static rm_status feedback_for(rm_ctx *ctx, hipStream_t stream, const uint64_t key[3], uint32_t n_tiles, rm_feedback **out) {
+    rm_feedback *f = nullptr;
+    for (rm_feedback &g : ctx->feedback)
+        if (g.stream == stream) f = &g;
+    if (!f) {
+        if (ctx->feedback.size() >= RM_FEEDBACK_STREAMS) {         // forget the stream used longest ago
+            size_t old = 0;
+            for (size_t i = 1; i < ctx->feedback.size(); i++)
+                if (ctx->feedback[i].used < ctx->feedback[old].used) old = i;
+            if (ctx->feedback[old].block) RM_HIP(ctx, hipFree(ctx->feedback[old].block));   // (waits for the device)
+            ctx->feedback.erase(ctx->feedback.begin() + (long)old);
+        }
+        ctx->feedback.emplace_back();
+        f = &ctx->feedback.back();
+        f->stream = stream;
+    }
+    f->used = ++ctx->feedback_clock;
+    const bool same = f->block && f->n_tiles == n_tiles && std::memcmp(f->key, key, sizeof f->key) == 0;
+    if (!same) {
+        const uint32_t cap = std::max(64u, (n_tiles + 7u) / 8u);
+        const size_t set_bytes = (((size_t)cap + RM_FB_BUCKETS + 4u) * sizeof(uint32_t) + n_tiles + 255u) & ~(size_t)255u;
+        if (!f->block || f->set_bytes != set_bytes) {
+            if (f->block) RM_HIP(ctx, hipFree(f->block));
+            f->block = nullptr;
+            RM_HIP(ctx, hipMalloc(&f->block, 3u * set_bytes + 256u));
+        }
+        f->set_bytes = set_bytes; f->cap = cap; f->n_tiles = n_tiles; f->cur = 0;
+        std::memcpy(f->key, key, sizeof f->key);
+        RM_HIP(ctx, hipMemsetAsync(f->block, 0, 3u * set_bytes + 256u, stream));
+    }
+    *out = f;
     return RM_OK;
 }
 
@@ -808,7 +884,33 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     const dim3 block(m.waves * 64);
     const void *fn = k.fn;
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
-    const dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
+    dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
+    // Feedback where tile costs have a long tail: deep ray trees in scenes with a hierarchy (a
+    // step of incoherent rays through it costs thirty coherent ones) and launches long enough for
+    // a tail to matter.  Elsewhere a tile costs its ray steps, the expensive rows are known (the
+    // ground: dispatched first) and the bookkeeping only costs -- measured with it forced on: demo
+    // scene 1080p 85.0 -> 87.7 us, 4K 306 -> 328, 8K depth 8 1,205 -> 1,375, Cornell box 72 -> 77.
+    rm_feedback *fb = nullptr;
+    const bool want_feedback = ctx->feedback_mode == 1 ||
+                               (ctx->feedback_mode < 0 && k.bvh && p->max_depth >= 6u && a.n_tiles >= RM_FEEDBACK_MIN_TILES);
+    if (want_feedback && per_wg == 1u && !ctx->debug_empty) {
+        const uint64_t key[3] = {(uint64_t)a.n_tiles | ((uint64_t)p->frame_width << 32),
+                                 (uint64_t)row_begin | ((uint64_t)band.stride << 32), ctx->scene_epoch};
+        rm_status fst = feedback_for(ctx, stream, key, a.n_tiles, &fb);
+        if (fst != RM_OK) return fst;
+        const int r = fb->cur, w = (fb->cur + 1) % 3, z = (fb->cur + 2) % 3;
+        a.fb_list = fb->list(r); a.fb_count = fb->count(r); a.fb_flag = fb->flag(r); a.fb_hist = fb->hist(r);
+        a.fb_next_list = fb->list(w); a.fb_next_count = fb->count(w); a.fb_next_flag = fb->flag(w); a.fb_next_hist = fb->hist(w);
+        a.fb_zero = fb->hist(z);
+        a.fb_threshold = fb->threshold();
+        a.fb_cap = fb->cap;
+        a.fb_long_ticks = ctx->feedback_us * 100u;            // s_memrealtime: 100 MHz
+        // longest-first scheduling needs the longest tiles first, a few per wave slot: the rest fill in
+        const uint32_t slots = (uint32_t)ctx->prop.multiProcessorCount * 16u;
+        a.fb_target = ctx->feedback_target >= 0 ? (uint32_t)ctx->feedback_target : 4u * slots;
+        a.fb_target = std::min(a.fb_target, fb->cap / 2u);
+        grid.x = a.n_tiles + fb->cap;                         // ids [0, cap): the list; the rest: the tiles in order
+    }
     if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     unsigned long long *d_stamps = nullptr;
@@ -819,6 +921,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
 #endif
     void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
+    if (fb) fb->cur = (fb->cur + 1) % 3;
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     RM_HIP(ctx, hipStreamSynchronize(stream));
     if (const char *path = std::getenv("RM_DEBUG_STAMPS")) {

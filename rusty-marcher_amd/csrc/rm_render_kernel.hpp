@@ -62,7 +62,33 @@ struct KernelArgs {
     // kernel's own operations: bp_x[x] = 2 (x / width - 0.5) half_fov ratio, bp_y[y] = -2 (y / height - 0.5) half_fov
     const double *bp_x, *bp_y;
     unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
+    // Frame-to-frame feedback (rm_device.hip, rm_feedback): the tiles that took longest in the
+    // previous frame on this stream are dispatched first.  fb_flag == NULL: off.
+    const uint32_t *fb_list;                 // previous frame: its long tiles, fb_count[0] of them (at most fb_cap)
+    const uint32_t *fb_count;
+    const uint8_t *fb_flag;                  // previous frame: 1 per tile that is on the list
+    const uint32_t *fb_hist;                 // previous frame: its tiles by time, RM_FB_BUCKETS buckets (sampled)
+    uint32_t *fb_next_list, *fb_next_count, *fb_next_hist;   // what this frame leaves for the next
+    uint8_t *fb_next_flag;
+    uint32_t *fb_zero;                       // counter and histogram of the frame after next: cleared by this one
+    uint32_t *fb_threshold;                  // ticks from which a tile is long: set by this frame's first wave
+    uint32_t fb_cap;                         // workgroups [0, fb_cap) take the list, the rest the tiles in order
+    uint32_t fb_long_ticks;                  // the threshold while there is no histogram (100 MHz ticks)
+    uint32_t fb_target;                      // tiles the list should hold (0: fb_long_ticks is the threshold)
 };
+
+// Feedback histogram: tile times in 100 MHz ticks, four buckets per octave (bucket b holds
+// [edge(b), edge(b+1)), edge(b) = (4 + b % 4) << (b / 4) >> 2: 1, 1, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7, 8, 10, ...);
+// every RM_FB_SAMPLE-th tile is counted.
+#define RM_FB_BUCKETS 64u
+#define RM_FB_SAMPLE 8u
+__device__ __forceinline__ uint32_t fb_bucket(uint32_t ticks) {
+    const uint32_t t = ticks < 4u ? 4u : ticks;
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(t);            // t in [2^e, 2^(e+1)), e >= 2
+    const uint32_t b = 4u * (e - 2u) + ((t >> (e - 2u)) & 3u);
+    return b < RM_FB_BUCKETS ? b : RM_FB_BUCKETS - 1u;
+}
+__device__ __forceinline__ uint32_t fb_edge(uint32_t b) { return (4u + (b & 3u)) << (b >> 2); }   // lower edge of bucket b
 
 // Copies a wave-uniform value into a scalar register of its own (see the kernel's header copy).
 // (a real move: an empty asm with a tied operand is coalesced back into the tuple)
@@ -100,15 +126,20 @@ __device__ __forceinline__ void stage_scene(const double *__restrict__ scene_blo
 
 // tile id -> pixel origin.  Patch-major: patch = id / 16 walks the band row by row
 // (renderer.rs:69-70), sub = id % 16 walks the 4x4 tiles of the patch.
-__device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t id, uint32_t &tx0, uint32_t &ty0, uint32_t &tyf,
-                                            uint32_t &ty8) {
-    // Workgroups are dispatched in id order; the affine map (a bijection: order_mul is
-    // coprime with n_tiles) decides which part of the image is rendered when.
-    // (natural and bottom-up order, the two that ship, without the 64-bit modulo)
+// dispatch id -> tile.  Workgroups are dispatched in id order; the affine map (a bijection:
+// order_mul is coprime with n_tiles) decides which part of the image is rendered when.
+// (natural and bottom-up order, the two that ship, without the 64-bit modulo)
+__device__ __forceinline__ uint32_t tile_of_id(const KernelArgs &a, uint32_t id) {
     const uint32_t last = a.n_tiles - 1u;
-    const uint32_t tile = (a.order_mul == 1u && a.order_add == 0u) ? id
-                        : (a.order_mul == last && a.order_add == last) ? last - id
-                        : (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
+    return (a.order_mul == 1u && a.order_add == 0u) ? id
+         : (a.order_mul == last && a.order_add == last) ? last - id
+         : (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
+}
+
+// tile -> pixel origin.  Patch-major: patch = tile / 16 walks the band row by row
+// (renderer.rs:69-70), sub = tile % 16 walks the 4x4 tiles of the patch.
+__device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, uint32_t &tx0, uint32_t &ty0, uint32_t &tyf,
+                                            uint32_t &ty8) {
     const uint32_t patch = tile >> 4, sub = tile & 15u;
     const uint32_t pcol = patch % a.n_width, prow = patch / a.n_width;
     tx0 = pcol * 32u + (sub & (32u / TILE_W - 1u)) * TILE_W;

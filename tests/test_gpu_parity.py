@@ -624,6 +624,56 @@ def test_bundle_cull_equals_plain_walk_bitwise(pkg, ctx, monkeypatch):
         plain_ctx.close()
 
 
+def test_feedback_order_renders_every_tile_once(pkg, ctx, monkeypatch):
+    """Frame-to-frame feedback (rm_device.hip, rm_feedback): the tiles that took long in the
+    previous frame on a stream are dispatched first in the next.  Only the ORDER of dispatch may
+    change: every frame of a sequence -- same camera, moved camera, another frame size, another
+    scene in between -- must equal the frame of a context without feedback bit for bit.  Forced
+    on for every launch (RM_FEEDBACK=1): with fixed thresholds (RM_FEEDBACK_TARGET=0) that put nearly
+    every tile (1 us: the list overflows its capacity), some tiles (8 us) and hardly any tile (200 us)
+    on the list, and with the threshold taken from the previous frame's histogram of tile times so
+    that the list holds about 40 tiles / as many as it is allowed to (the default's two per wave slot
+    exceed half the list's capacity at these frame sizes)."""
+    monkeypatch.setenv("RM_FEEDBACK", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_FEEDBACK", "1")
+    ctxs = []
+    for us, target in (("1", "0"), ("8", "0"), ("200", "0"), ("50", "40"), ("50", None)):
+        monkeypatch.setenv("RM_FEEDBACK_US", us)
+        if target is None:
+            monkeypatch.delenv("RM_FEEDBACK_TARGET")
+        else:
+            monkeypatch.setenv("RM_FEEDBACK_TARGET", target)
+        ctxs.append(pkg.backend.Context(0))
+    monkeypatch.delenv("RM_FEEDBACK_US")
+    monkeypatch.delenv("RM_FEEDBACK")
+    synth = workloads.product_scene(pkg, "synthetic256")
+    demo = pkg.Scene.create_default()
+    seq = [(synth, (0., 0., 0.), 512, 384, 8), (synth, (0., 0., 0.), 512, 384, 8), (synth, (0., 0., 0.), 512, 384, 8),
+           (synth, (2., 1., -5.), 512, 384, 8), (synth, (2., 1., -5.), 512, 384, 10), (synth, (2., 1., -5.), 640, 352, 10),
+           (demo, (0., 0., 0.), 640, 352, 5), (demo, (0., 5., 0.), 640, 352, 5), (demo, (0., 5., 0.), 640, 352, 5),
+           (synth, (0., 0., 0.), 640, 352, 6), (synth, (0., 0., 0.), 640, 352, 6)]
+    try:
+        for k, (scene, cam, w, h, depth) in enumerate(seq):
+            scene.camera = pkg.Vec3f(*cam)
+            want, _ = gpu_render(pkg, plain, scene, w, h, depth)
+            assert (want.sum(axis=2) > 0).any()
+            for c in ctxs:
+                got = np.full((h, w, 3), -1., dtype=np.float64)         # a tile left out would keep its -1
+                gpu_render(pkg, c, scene, w, h, depth, out=got)
+                assert np.array_equal(got, want), "frame %d of the sequence differs with feedback on" % k
+        # bands of a sharded frame (another launch geometry on the same stream, back and forth)
+        for band in ((0, 11, 2), (1, 11, 2), (0, 11, 2)):
+            want = np.zeros((352, 640, 3)); got = np.zeros((352, 640, 3))
+            gpu_render(pkg, plain, synth, 640, 352, 6, band=band, out=want)
+            gpu_render(pkg, ctxs[1], synth, 640, 352, 6, band=band, out=got)
+            assert np.array_equal(got, want)
+    finally:
+        plain.close()
+        for c in ctxs:
+            c.close()
+
+
 # ---------------------------------------------------------------- properties at full size
 def test_bands_tile_the_frame_bitwise(pkg, ctx):
     """Row sharding: the union of per-rank bands is bit-identical to the
