@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+V=$GRAFT_REPO_ROOT/rusty-marcher_amd/lib/variants
+P="RM_LIB_PATH=$V/bplate/librusty_marcher_amd.so"
+S="RM_LIB_PATH=$V/s0/librusty_marcher_amd.so"
+echo "== C2"; printf "RM_X=0\n$P\n$S\nRM_X=0\n$P\n$S\n" | bash profiles/ab_env.sh --config C2 --steps 200
+echo "== C4"; printf "RM_X=0\n$P\n$S\nRM_X=0\n$P\n$S\n" | bash profiles/ab_env.sh --config C4 --steps 20
+echo "== C3"; printf "RM_X=0\n$P\n$S\n" | bash profiles/ab_env.sh --config C3

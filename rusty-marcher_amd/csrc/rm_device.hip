@@ -232,15 +232,15 @@ static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 // (W waves per workgroup, one tile per wave; STAGED: LDS copy of the scene for the per-lane
 // gathers; BVH: hierarchy walk for wide bundles; CULL: bundle culling, EDGES: its edge test
 // for planar primitives, rm_trace.inc).
-template <int W, bool STAGED, bool BVH, bool CULL, bool EDGES>
+template <int W, bool STAGED, bool BVH, bool CULL, bool EDGES, bool FB = false>
 static const void *pick_kernel(int stack, int pow_mode, bool fast) {
 #define RM_ROW(S)                                                                                    \
     if (stack == S) {                                                                                \
         if (fast)                                                                                    \
-            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES>   \
-                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES>;  \
-        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES>     \
-                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES>;    \
+            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES, FB>   \
+                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES, FB>;  \
+        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES, FB>     \
+                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES, FB>;    \
     }
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
@@ -779,10 +779,10 @@ struct rm_kernel_choice {
     rm_launch_mode mode;
     size_t lds_bytes = 0;
     int stack = 0, pow_mode = 0;
-    bool fast = false, staged = false, bvh = false, cull = false, edges = false;
+    bool fast = false, staged = false, bvh = false, cull = false, edges = false, feedback = false;
 };
 
-static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice *k) {
+static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, rm_kernel_choice *k) {
     // launch geometry: one tile per wave, one wave per workgroup; small scenes get an LDS copy
     // of the scene for the per-lane gathers, larger ones none
     const size_t scene_bytes = (size_t)ctx->H.total_words * sizeof(double);
@@ -809,7 +809,17 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, rm_kernel_choice
     k->edges = k->cull && ctx->H.n_polygons + ctx->H.n_triangles >= RM_CULL_EDGES_MIN_PLANAR;
     const int st = k->stack, pw = k->pow_mode;
     const bool f = k->fast;
-    k->fn = !k->staged ? (k->bvh ? (k->edges ? pick_kernel<1, false, true, true, true>(st, pw, f) : pick_kernel<1, false, true, true, false>(st, pw, f))
+    // Feedback where tile costs have a long tail: deep ray trees in scenes with a hierarchy (a
+    // step of incoherent rays through it costs thirty coherent ones) and launches long enough for
+    // a tail to matter.  Elsewhere a tile costs its ray steps, the expensive rows are known (the
+    // ground: dispatched first) and the bookkeeping only costs -- measured with it forced on: demo
+    // scene 1080p 85.0 -> 87.7 us, 4K 306 -> 328, 8K depth 8 1,205 -> 1,375, Cornell box 72 -> 77.
+    // RM_FEEDBACK=1 forces it for every launch of a kernel with the hierarchy walk, =0 switches it off.
+    k->feedback = k->bvh && ctx->feedback_mode != 0 && !ctx->debug_empty &&
+                  (ctx->feedback_mode == 1 || (p->max_depth >= 6u && tiles >= RM_FEEDBACK_MIN_TILES));
+    k->fn = !k->staged && k->bvh && k->feedback
+                       ? (k->edges ? pick_kernel<1, false, true, true, true, true>(st, pw, f) : pick_kernel<1, false, true, true, false, true>(st, pw, f))
+          : !k->staged ? (k->bvh ? (k->edges ? pick_kernel<1, false, true, true, true>(st, pw, f) : pick_kernel<1, false, true, true, false>(st, pw, f))
                                  : (k->edges ? pick_kernel<1, false, false, true, true>(st, pw, f) : pick_kernel<1, false, false, true, false>(st, pw, f)))
           : k->cull    ? (k->edges ? pick_kernel<1, true, false, true, true>(st, pw, f) : pick_kernel<1, true, false, true, false>(st, pw, f))
                        : pick_kernel<1, true, false, false, false>(st, pw, f);
@@ -877,7 +887,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     }
 
     rm_kernel_choice k;
-    rm_status st = choose_kernel(ctx, p, &k);
+    rm_status st = choose_kernel(ctx, p, a.n_tiles, &k);
     if (st != RM_OK) return st;
     const rm_launch_mode m = k.mode;
     const size_t lds = k.lds_bytes;
@@ -885,14 +895,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     const void *fn = k.fn;
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
     dim3 grid((a.n_tiles + per_wg - 1) / per_wg);
-    // Feedback where tile costs have a long tail: deep ray trees in scenes with a hierarchy (a
-    // step of incoherent rays through it costs thirty coherent ones) and launches long enough for
-    // a tail to matter.  Elsewhere a tile costs its ray steps, the expensive rows are known (the
-    // ground: dispatched first) and the bookkeeping only costs -- measured with it forced on: demo
-    // scene 1080p 85.0 -> 87.7 us, 4K 306 -> 328, 8K depth 8 1,205 -> 1,375, Cornell box 72 -> 77.
     rm_feedback *fb = nullptr;
-    const bool want_feedback = ctx->feedback_mode == 1 ||
-                               (ctx->feedback_mode < 0 && k.bvh && p->max_depth >= 6u && a.n_tiles >= RM_FEEDBACK_MIN_TILES);
+    const bool want_feedback = k.feedback;
     if (want_feedback && per_wg == 1u && !ctx->debug_empty) {
         const uint64_t key[3] = {(uint64_t)a.n_tiles | ((uint64_t)p->frame_width << 32),
                                  (uint64_t)row_begin | ((uint64_t)band.stride << 32), ctx->scene_epoch};
@@ -1032,12 +1036,12 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     if (st != RM_OK) return st;
     if (params->max_depth == 0) { std::snprintf(buf, buflen, "rm_fill_band_kernel"); return RM_OK; }
     rm_kernel_choice k;
-    st = choose_kernel(ctx, params, &k);
+    st = choose_kernel(ctx, params, band.count() * (params->frame_width / RM_PATCH_SIZE) * 16u, &k);
     if (st != RM_OK) return st;
     // the name rocprofv3's kernel trace shows (template arguments in declaration order)
-    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
-                  k.cull ? "true" : "false", k.edges ? "true" : "false");
+                  k.cull ? "true" : "false", k.edges ? "true" : "false", k.feedback ? "true" : "false");
     return RM_OK;
 }
 
