@@ -766,6 +766,10 @@ def rank_main(args):
                           "kernel": o["kernel_name"], "kernel_ms": o["best"]["kernel_ms"] if world == 1 else None,
                           "collective": o["chosen"],
                           "roofline_frac": (ach / HBM_PEAK_GBPS) if world == 1 else None})
+            if o["kernel_name"].rstrip(">").endswith("true"):         # last template argument: FEEDBACK
+                other[-1]["dispatch"] = ("frame-to-frame feedback: the tiles that took longest in the previous frame on the "
+                                         "stream are dispatched first (RM_FEEDBACK=0 switches it off); every tile of every "
+                                         "frame is rendered in full")
             o.clear()
 
     if rank == 0:
