@@ -813,6 +813,49 @@ def test_frame_submit_through_rccl_world_of_one(pkg):
     cx.close()
 
 
+def test_feedback_with_frames_in_flight(pkg, monkeypatch):
+    """Frame-to-frame feedback under rm_frame_submit: every frame slot renders on a stream of its
+    own and keeps feedback sets of its own; three ranks' cyclic bands (layout without a transport,
+    the ranks taking turns on this GPU, rank r on slot r) over four rounds with the camera moving
+    every other round -- each round's assembled frame must be the single-GPU frame of a context
+    without feedback, bit for bit (f64 rows and display bytes)."""
+    import torch
+    w, h, depth, world = 640, 352, 8, 3
+    n_rows = h // 32
+    scene = workloads.product_scene(pkg, "synthetic256")
+    monkeypatch.setenv("RM_FEEDBACK", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_FEEDBACK", "1")
+    monkeypatch.setenv("RM_FEEDBACK_TARGET", "24")
+    cx = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_FEEDBACK_TARGET")
+    monkeypatch.delenv("RM_FEEDBACK")
+    try:
+        p = pkg.backend.make_params(1.5, float(h), float(w), depth)
+        p.flags = _FLAGS["value"]
+        rows, chunk = cx.exchange_layout(p, world)
+        full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        full8 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+        for rnd, cam in enumerate([(0., 0., 0.), (0., 0., 0.), (1., 1., -4.), (1., 1., -4.)]):
+            scene.camera = pkg.Vec3f(*cam)
+            plain.upload(scene.flatten())
+            cx.upload(scene.flatten())
+            plain.render_device_u8(p, full.data_ptr(), full8.data_ptr())
+            torch.cuda.synchronize()
+            parts = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+            gathered = torch.full((world * chunk,), 7, dtype=torch.uint8, device="cuda:0")
+            display = torch.full((n_rows * 32, w, 3), 9, dtype=torch.uint8, device="cuda:0")
+            for r in range(world):
+                cx.comm_init(r, world)
+                cx.frame_submit(p, parts.data_ptr(), gathered.data_ptr(), display.data_ptr() if r == world - 1 else None, slot=r)
+                cx.frame_wait(r)                                # (the last rank de-interleaves what the others wrote)
+            assert torch.equal(parts, full), "round %d: f64 rows" % rnd
+            assert torch.equal(display, full8[:n_rows * 32]), "round %d: display bytes" % rnd
+    finally:
+        plain.close()
+        cx.close()
+
+
 @pytest.mark.parametrize("world", [1, 2, 5, 8])
 def test_frame_submit_f64_layout_of_n_ranks_on_one_gpu(pkg, world):
     """rm_frame_submit_f64: the f64 rows themselves travel (framebuffer.rs:6-22: the reference's
