@@ -48,7 +48,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PIXEL = 24            # 3 x f64 written per pixel (framebuffer.rs Vec3f), SURVEY.md 8d
+FEEDBACK_NOTE = ("frame-to-frame feedback: the tiles that took longest in the previous frame on the stream are dispatched "
+                 "first (RM_FEEDBACK=0 switches it off); every tile of every frame is rendered in full")
 WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
+WARMUP_PROBE = 8                # launches timed to find out how many that is
 
 
 def parse_args(argv=None):
@@ -492,18 +495,24 @@ def rank_main(args):
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()                 # (the barrier is a collective on the device)
 
         def timed(step, direct):
             """--warmup steps + launches until WARMUP_SECONDS have passed (the same count on
             every rank), then EXACTLY `steps` steps between fences; max over ranks."""
             counter[0] = 0
-            t_w = time.perf_counter()
             for _ in range(warmup):
                 step()
             fence(direct)
-            per = (time.perf_counter() - t_w) / max(warmup, 1)
-            extra = torch.tensor([int(max(0., WARMUP_SECONDS - per * warmup) / max(per, 1e-6)) + 1], dtype=torch.int64, device=dev)
+            # how many launches fill WARMUP_SECONDS: from a batch that no longer pays for the first
+            # launch of the process (module load, buffers: milliseconds -- counted into the estimate
+            # they cut the time-based warm-up of a --warmup 5 run to a few dozen launches)
+            t_w = time.perf_counter()
+            for _ in range(WARMUP_PROBE):
+                step()
+            fence(direct)
+            per = (time.perf_counter() - t_w) / WARMUP_PROBE
+            extra = torch.tensor([int(WARMUP_SECONDS / max(per, 1e-6)) + 1], dtype=torch.int64, device=dev)
             if use_dist:
                 dist.broadcast(extra, src=0)
             for _ in range(min(int(extra.item()), 20000)):
@@ -735,6 +744,8 @@ def rank_main(args):
                          "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); achieved = 24 B x pixels "
                                  "written / kernel time (HIP events on the launch stream); " + pmc_note},
         }
+        if kernel_name.rstrip(">").endswith("true"):                 # last template argument: FEEDBACK
+            out["config"]["dispatch"] = FEEDBACK_NOTE
         if world > 1 or args.force_dist:
             out["exchange_paths"] = paths
         if checks:
@@ -767,9 +778,7 @@ def rank_main(args):
                           "collective": o["chosen"],
                           "roofline_frac": (ach / HBM_PEAK_GBPS) if world == 1 else None})
             if o["kernel_name"].rstrip(">").endswith("true"):         # last template argument: FEEDBACK
-                other[-1]["dispatch"] = ("frame-to-frame feedback: the tiles that took longest in the previous frame on the "
-                                         "stream are dispatched first (RM_FEEDBACK=0 switches it off); every tile of every "
-                                         "frame is rendered in full")
+                other[-1]["dispatch"] = FEEDBACK_NOTE
             o.clear()
 
     if rank == 0:
