@@ -84,11 +84,13 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // waves per workgroup, `per_wave` tiles per wave.  Measured at 1080p on the demo scene
 // (profiles/r01_ab_launch_modes.txt): one tile per wave wins (finer units for the
 // hardware dispatcher: 4 tiles per wave 193 us vs 1 tile 122 us); 1 or 4 waves per
-// workgroup differ by ~2 %, so larger scenes share one LDS copy between 4 waves.
+// workgroup differ by ~2 % there -- but not where tile costs differ widely: a slot freed by a
+// workgroup of four is handed on only when a whole workgroup fits (256 spheres: 1,777 us with
+// four waves, 1,420 with one).
 // A persistent variant (waves pulling tiles from a global counter) was measured too and
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
-// This build instantiates one tile per wave only (1 wave per workgroup with the LDS scene
-// copy, 4 without); the other geometries were measured with earlier builds.
+// This build instantiates one tile per wave, one wave per workgroup only; the other geometries
+// were measured with earlier builds.
 static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4, RM_CULL_MAX_COST = 250;
 static inline uint32_t k_planar_from(const rm_dev_header &H) { return H.n_spheres; }   // pid of the first planar primitive
 
