@@ -114,14 +114,41 @@ def _kill_group(proc):
             pass
 
 
+def visible_gpus():
+    """GPUs this process could open, counted WITHOUT touching the HIP runtime: the KFD topology
+    nodes that have SIMDs (CPU nodes have none; a node this container may not use does not read:
+    the driver checks the device cgroup), less what HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+    leave.  None when the topology is not there to read."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            for ln in open(path):
+                if ln.startswith("simd_count"):
+                    n += 1 if int(ln.split()[1]) > 0 else 0
+        except (OSError, ValueError, IndexError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
     """--gpus N > 1 without a launcher: start N copies of this file (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment), relay rank 0's JSON line, return the exit
-    code.  Nothing here initialises a GPU: torch.cuda.device_count() only counts."""
+    code.  Nothing here touches the HIP runtime: the GPUs are counted from the KFD topology in
+    sysfs (torch.cuda.device_count() only where that is not readable)."""
     n = args.gpus
     if not args.dry_run and os.environ.get("RM_BENCH_BACKEND", "nccl") == "nccl":
-        import torch
-        have = torch.cuda.device_count()
+        have = visible_gpus()
+        if have is None:
+            import torch
+            have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write("bench.py --gpus %d needs %d GPUs; this node shows %d\n" % (n, n, have))
             return 2
@@ -617,7 +644,7 @@ def rank_main(args):
             med = float(np.median(ts))
             host = {"value": w * h / med / 1e6, "unit": "Mpixels/s", "ms_per_frame": med * 1e3,
                     "kernel_ms": tm.kernel_ms, "d2h_ms": tm.d2h_ms,
-                    "what": "rm_render(): kernel + device-to-host copy of the f64 frame into the caller's pageable memory, median of 10"}
+                    "what": "rm_render(): kernel + device-to-host copy of the f64 frame (the patches that are not black) into the caller's flat pageable memory, median of 10"}
             # the same call into page-locked memory from rm_host_alloc -- what the Rust shim's
             # staging buffer is
             hp = C.c_void_p()
@@ -634,6 +661,35 @@ def rank_main(args):
                                                "d2h_ms": tm.d2h_ms, "identical": bool(np.array_equal(pinned, host_frame))}
             del pinned
             L.rm_host_free(ctx.ptr, hp)
+            st = ctx.hostio_stats()
+            host["bytes_over_the_link"] = st["bytes_copied"]
+            host["patches_sent"] = "%d of %d (black 32x32 patches are written by the host, not sent)" % (st["patches_sent"], st["patches"])
+            # The seam the reference really has: its FrameBuffer is Vec<Vec<Vec3f>>, one
+            # heap allocation per scan line (framebuffer.rs:6-22), and its window consumes fb.to_vec()
+            # (main.rs:337-346).  rm_seam is compiled host code over the C ABI holding exactly that --
+            # a std::vector per row -- run here as a child process while this one idles.
+            seam = os.path.join(G.PKG_DIR, "lib", "rm_seam")
+            if os.path.exists(seam):
+                try:
+                    cmd = [seam, "--width", str(w), "--height", str(h), "--depth", str(depth), "--frames", "20"]
+                    if cfg["scene"] == "cornell":
+                        cmd += ["--scene", workloads.CORNELL]
+                    if args.fast_fp:
+                        cmd += ["--fast-fp"]
+                    if cfg["scene"] in ("demo", "cornell"):
+                        pr = subprocess.run(cmd, capture_output=True, timeout=300)
+                        line = pr.stdout.decode().strip().splitlines()[-1] if pr.stdout.strip() else ""
+                        if pr.returncode == 0 and line.startswith("{"):
+                            sj = json.loads(line)
+                            host["rows_of_rows"] = dict(sj["rows_of_rows"], value=sj["rows_of_rows"]["mpx_per_s"], unit="Mpixels/s",
+                                                        host_threads=sj["host_threads"])
+                            host["display_only"] = sj["display_only"]
+                            host["fetch_rows_ms"] = sj["fetch_rows"]["ms_per_call"]
+                            host["flat_from_compiled_code"] = sj["flat"]
+                        else:
+                            host["rows_of_rows"] = {"error": "rm_seam exited with %d: %s" % (pr.returncode, pr.stderr.decode()[-300:])}
+                except Exception as e:                   # noqa: BLE001 -- an extra beside the metric: reported, not fatal
+                    host["rows_of_rows"] = {"error": "rm_seam: %s" % e}
             # the same frames with four in flight, each on a stream of its own (rm_frame_submit with no
             # communicator): what a renderer gets that need not wait for frame k before starting
             # k+1 -- the ramp and drain of one frame fill with the others.  Not the metric: a step
@@ -788,6 +844,17 @@ def rank_main(args):
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, r["cfg"])
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # ... and at the seam: the drop-in call itself, frame in host memory, against the same CPU path
+            e2e = out.get("end_to_end_host") or {}
+            cpu_v = out["cpu_baseline"]["value"]
+            at_seam = {"kernel_only_device_resident": out["speedup_vs_cpu_baseline"]}
+            if e2e.get("value"):
+                at_seam["rm_render_flat_pageable"] = e2e["value"] / cpu_v
+            if (e2e.get("rows_of_rows") or {}).get("value"):
+                at_seam["rm_render_rows_rows_of_rows"] = e2e["rows_of_rows"]["value"] / cpu_v
+            if (e2e.get("display_only") or {}).get("frames_per_s"):
+                at_seam["rm_render_display_display_bytes"] = e2e["display_only"]["frames_per_s"] * (r["cfg"]["width"] * r["cfg"]["height"]) / 1e6 / cpu_v
+            out["speedup_vs_cpu_baseline_at_the_seam"] = at_seam
         emit(out)
 
     if use_dist:

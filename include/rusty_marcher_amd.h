@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 2u
+#define RM_ABI_VERSION 3u
 
 typedef enum rm_status {
     RM_OK = 0,
@@ -47,7 +47,8 @@ typedef enum rm_status {
     RM_ERR_COMM = 10,        /* RCCL unavailable or a collective failed (rm_comm_*, rm_frame_*) */
     RM_ERR_TIMEOUT = 11      /* rm_frame_wait*: the slot's frame did not complete in time (a peer is
                                 missing or stuck in the collective); the context is not usable for
-                                further frames -- report and exit */
+                                further frames -- report and exit (rm_destroy then releases what it
+                                can without waiting for the device) */
 } rm_status;
 
 /* Recursion cap accepted by rm_render.  The reference hard-codes 3
@@ -235,9 +236,53 @@ rm_status rm_camera_update(rm_ctx *ctx, rm_vec3 camera);
  * reference.  NULL leaves the result in the context's device framebuffer.
  * Blocks until host_rgb is filled (or, for NULL, until the kernel has finished).
  * The device -> host copy dominates the call (48.7 MB at 1080p: ~0.9 ms over PCIe against
- * 0.09 ms of kernel); a display loop wants rm_frame_submit_to_host (3 B/pixel) instead.
+ * 0.08 ms of kernel; black patches are not sent, see rm_render_rows); a window wants
+ * rm_render_display (3 B/pixel), a render loop rm_frame_submit_to_host.
  */
 rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing);
+
+/*
+ * Renderer::render into the reference's ACTUAL render target: framebuffer.rs:6-22 is
+ * `buffer: Vec<Vec<Vec3f>>`, one heap allocation per scan line, filled by the serial scatter of
+ * renderer.rs:92-108.  rows[y] points at row y: frame_width * 3 doubles (x, y, z of each Vec3f --
+ * `#[repr(C)]` on geometry.rs:4-8); frame_height pointers, of which only
+ * those of the band's rows are read (the others may be NULL: rows >= frame_height -
+ * frame_height % 32 keep their contents, renderer.rs:53).  Blocks until the rows are filled, bit
+ * for bit what rm_render writes into a flat array.
+ * Inside: one launch, then the frame crosses the PCIe link into a page-locked staging buffer of
+ * the context in chunks while a few host threads (RM_HOST_THREADS, default min(8, cores))
+ * scatter the chunks that have arrived into the rows.  Patches that are black -- +0.0 in every
+ * channel of all 1,024 pixels: what primary rays that leave the scene produce, renderer.rs:305 --
+ * are not sent: a kernel packs the others, the host writes the zeros itself (frames of 2 MB and
+ * more; RM_HOST_PACK=0|1 forces).  rm_render takes the same path into its flat array.
+ */
+rm_status rm_render_rows(rm_ctx *ctx, const rm_params *params, double *const *rows, rm_timing *timing);
+
+/*
+ * Renderer::render with a DEVICE-RESIDENT FrameBuffer: the f64 frame stays in the context's
+ * device framebuffer (rm_device_framebuffer, rm_fetch_rows, rm_postprocess(ctx, NULL, ..)) and
+ * only `fb.to_vec()` of the band -- the bytes update_raytrace_image hands to the pixbuf,
+ * main.rs:337-346; (255 * clamp(f, 0, 1)) as u8, framebuffer.rs:40-55,80-82 -- comes back:
+ * host_rgb8 is [frame_height][frame_width][3] bytes, only the band's rows are written.  3 B/pixel
+ * instead of 24, and the frame is rendered as a few sub-bands (RM_DISPLAY_SUBBANDS, default 3),
+ * the bytes of one crossing the link while the next renders.  Blocks until host_rgb8 is filled.
+ * host_rgb8 from rm_host_alloc is written by the copy engine directly; any other memory is
+ * reached through the context's staging buffer.
+ */
+rm_status rm_render_display(rm_ctx *ctx, const rm_params *params, uint8_t *host_rgb8, rm_timing *timing);
+
+/*
+ * f64 rows of the device-resident frame on demand (save_to_file, main.rs:353-357: normalize +
+ * write_ppm read the f64 values): patch rows [patch_row_begin, patch_row_end) -- end 0 = all
+ * whole patch rows -- of the frame the last rm_render / rm_render_rows / rm_render_display left
+ * on the device, into rows[y] (as rm_render_rows).
+ */
+rm_status rm_fetch_rows(rm_ctx *ctx, double *const *rows, uint32_t patch_row_begin, uint32_t patch_row_end);
+
+/* What the last rm_render / rm_render_rows / rm_fetch_rows / rm_render_display of this context
+ * moved: bytes that crossed the link, 32x32 patches of the band, patches among them that were
+ * sent (the others were black and written by the host), and the host threads that scatter. */
+rm_status rm_hostio_stats(rm_ctx *ctx, uint64_t *bytes_copied, uint64_t *patches, uint64_t *patches_sent, int *threads);
 
 /*
  * Same kernel, asynchronous, into a caller-owned DEVICE buffer with the same

@@ -45,6 +45,39 @@ class Context:
         _lib.check(self.L.rm_render(self.ptr, C.byref(params), ptr, C.byref(t)), self.ptr)
         return t
 
+    @staticmethod
+    def row_pointers(rows):
+        """double *const * for rm_render_rows / rm_fetch_rows: one pointer per row, each row a
+        float64 array of its own (the reference's Vec<Vec<Vec3f>>, framebuffer.rs:6-22); None for
+        rows the call must not touch."""
+        arr = (C.POINTER(C.c_double) * len(rows))()
+        for i, r in enumerate(rows):
+            if r is not None:
+                arr[i] = r.ctypes.data_as(C.POINTER(C.c_double))
+        return arr
+
+    def render_rows(self, params, rows):
+        """Renderer::render into rows of rows (rm_render_rows)."""
+        t = _lib.rm_timing()
+        _lib.check(self.L.rm_render_rows(self.ptr, C.byref(params), self.row_pointers(rows), C.byref(t)), self.ptr)
+        return t
+
+    def render_display(self, params, host_u8):
+        """Renderer::render with the f64 frame left on the device: only fb.to_vec() comes back."""
+        t = _lib.rm_timing()
+        _lib.check(self.L.rm_render_display(self.ptr, C.byref(params), host_u8.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            C.byref(t)), self.ptr)
+        return t
+
+    def fetch_rows(self, rows, patch_row_begin=0, patch_row_end=0):
+        _lib.check(self.L.rm_fetch_rows(self.ptr, self.row_pointers(rows), patch_row_begin, patch_row_end), self.ptr)
+
+    def hostio_stats(self):
+        """What the last host-bound call moved: bytes over the link, patches, patches sent, threads."""
+        b, p, s, t = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        _lib.check(self.L.rm_hostio_stats(self.ptr, C.byref(b), C.byref(p), C.byref(s), C.byref(t)), self.ptr)
+        return {"bytes_copied": b.value, "patches": p.value, "patches_sent": s.value, "threads": t.value}
+
     def render_device(self, params, device_ptr, stream=None):
         _lib.check(self.L.rm_render_device(self.ptr, C.byref(params), C.c_void_p(device_ptr),
                                            C.c_void_p(stream) if stream else None), self.ptr)

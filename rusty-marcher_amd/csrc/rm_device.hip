@@ -16,7 +16,7 @@
 
 #include "rm_bvh.hpp"
 #include "rm_internal.h"
-#include "rm_render_kernel.hpp"
+#include "rm_kernel_args.hpp"
 
 using namespace rmdev;
 
@@ -136,6 +136,8 @@ struct rm_feedback {
     uint32_t *threshold() const { return hist(3); }
 };
 
+struct rm_hostio;   // rm_hostio.inc: staging buffer, row-scatter threads, display frame
+
 struct rm_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -151,7 +153,8 @@ struct rm_ctx {
     rm_vec3 camera{0., 0., 0.};
     std::vector<double> host_blob;    // the device image of the resident scene (rm_scene_upload skips identical ones)
     uint64_t upload_calls = 0, upload_copies = 0;
-    uint64_t desc_digest[2] = {0, 0}; // of the description the resident image was built from
+    std::vector<unsigned char> desc_bytes;   // the description arrays the resident image was built from, back to back
+    size_t desc_sizes[6] = {0, 0, 0, 0, 0, 0};
     bool integer_exponents = false;   // every material's specular_exponent is a small non-negative integer
     bool force_generic_pow = false;   // RM_FORCE_GENERIC_POW=1 (A/B knob)
     bool force_fast_fp = false;       // RM_FORCE_FAST_FP=1 (A/B knob; same as RM_FLAG_FAST_FP on every call)
@@ -198,11 +201,20 @@ struct rm_ctx {
     size_t backproject_words = 0;
     double backproject_key[6] = {};
 
+    // the seam into the reference's FrameBuffer (rm_hostio.inc)
+    rm_hostio *hostio = nullptr;
+    bool comm_stuck = false;          // a timed-out collective could not be aborted: nothing that waits for the device may run
+
     // post-process scratch
     unsigned long long *d_max = nullptr;
     uint8_t *d_rgb8 = nullptr;
     size_t rgb8_bytes = 0;
 };
+
+static void hostio_destroy(rm_ctx *ctx, bool device_ok);
+struct rm_band;
+static bool hostio_packs(rm_ctx *ctx, size_t band_bytes);
+static rm_status hostio_frame_to_rows(rm_ctx *ctx, const rm_band &band, uint32_t frame_width, double *const *rows);
 
 static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
     if (ctx) ctx->error = msg;
@@ -230,29 +242,33 @@ static constexpr uint64_t RM_SCENE_MAX_WORDS = 0xFFFFFFF0ull;
 static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 
 
-// Kernel instantiation table: stack depth x pow flavour for one launch geometry
-// (W waves per workgroup, one tile per wave; STAGED: LDS copy of the scene for the per-lane
-// gathers; BVH: hierarchy walk for wide bundles; CULL: bundle culling, EDGES: its edge test
-// for planar primitives, rm_trace.inc).
-template <int W, bool STAGED, bool BVH, bool CULL, bool EDGES, bool FB = false>
-static const void *pick_kernel(int stack, int pow_mode, bool fast) {
-#define RM_ROW(S)                                                                                    \
-    if (stack == S) {                                                                                \
-        if (fast)                                                                                    \
-            return pow_mode == POW_INTEGER ? (const void *)rmdev_fast::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES, FB>   \
-                                           : (const void *)rmdev_fast::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES, FB>;  \
-        return pow_mode == POW_INTEGER ? (const void *)rmdev_strict::rm_render_static<S, POW_INTEGER, W, 1, STAGED, BVH, CULL, EDGES, FB>     \
-                                       : (const void *)rmdev_strict::rm_render_static<S, POW_GENERIC, W, 1, STAGED, BVH, CULL, EDGES, FB>;    \
+// The kernel instantiations live in rm_kernels.hip, one object per numeric flavour and kernel
+// group (STAGED: LDS copy of the scene for the per-lane gathers; BVH: hierarchy walk for wide
+// bundles; CULL: bundle culling, EDGES: its edge test for planar primitives, rm_trace.inc;
+// FEEDBACK: longest tiles of the previous frame first).
+#define RM_DECLARE_GROUP(g) \
+    const void *rm_pick_kernel_strict_g##g(bool edges, int stack, int pow_mode); \
+    const void *rm_pick_kernel_fast_g##g(bool edges, int stack, int pow_mode);
+RM_DECLARE_GROUP(0) RM_DECLARE_GROUP(1) RM_DECLARE_GROUP(2) RM_DECLARE_GROUP(3) RM_DECLARE_GROUP(4)
+#undef RM_DECLARE_GROUP
+
+const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool feedback, int stack, int pow_mode) {
+    const int group = staged ? (cull ? 1 : 0) : !bvh ? 2 : feedback ? 4 : 3;
+    if (staged && (bvh || feedback)) return nullptr;         // no such kernel: small scenes have no hierarchy
+    if (!staged && !cull) return nullptr;                    // scenes in global memory always cull
+    switch (group) {
+    case 0: return fast ? rm_pick_kernel_fast_g0(edges, stack, pow_mode) : rm_pick_kernel_strict_g0(edges, stack, pow_mode);
+    case 1: return fast ? rm_pick_kernel_fast_g1(edges, stack, pow_mode) : rm_pick_kernel_strict_g1(edges, stack, pow_mode);
+    case 2: return fast ? rm_pick_kernel_fast_g2(edges, stack, pow_mode) : rm_pick_kernel_strict_g2(edges, stack, pow_mode);
+    case 3: return fast ? rm_pick_kernel_fast_g3(edges, stack, pow_mode) : rm_pick_kernel_strict_g3(edges, stack, pow_mode);
+    default: return fast ? rm_pick_kernel_fast_g4(edges, stack, pow_mode) : rm_pick_kernel_strict_g4(edges, stack, pow_mode);
     }
-    RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
-#undef RM_ROW
-    return nullptr;
 }
 
 extern "C" {
 
 const char *rm_build_info(void) {
-    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi2";
+    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi3";
 }
 
 const char *rm_last_error(const rm_ctx *ctx) {
@@ -312,24 +328,34 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
 void rm_destroy(rm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream && !ctx->comm_failed) (void)hipStreamSynchronize(ctx->stream);
     rm_comm_destroy(ctx);
-    for (rm_frame_slot &s : ctx->slots) {
-        // after a timed-out collective the slot's stream never drains: leave it to process exit
-        if (s.render && !ctx->comm_failed) { (void)hipStreamSynchronize(s.render); (void)hipStreamDestroy(s.render); }
-        for (hipEvent_t e : {s.begun, s.rendered, s.gathered, s.exchanged})
-            if (e) (void)hipEventDestroy(e);
+    // A frame wait that timed out left a collective in flight.  Where RCCL could abort its
+    // communicator the device drains and everything below is safe; where it could not
+    // (ncclCommAbort absent or failing) the collective's kernel never ends, and hipFree /
+    // hipStreamSynchronize / hipStreamDestroy -- each waits for the device -- would hang for
+    // ever: the hang the timeout was there to remove.  Then nothing device-side is released:
+    // the process is about to exit (RM_ERR_TIMEOUT: "report and exit") and takes it along.
+    const bool device_ok = !ctx->comm_stuck;
+    hostio_destroy(ctx, device_ok);
+    if (device_ok) {
+        for (rm_frame_slot &s : ctx->slots) {
+            // after a timed-out collective the slot's stream may never drain: leave it to process exit
+            if (s.render && !ctx->comm_failed) { (void)hipStreamSynchronize(s.render); (void)hipStreamDestroy(s.render); }
+            for (hipEvent_t e : {s.begun, s.rendered, s.gathered, s.exchanged})
+                if (e) (void)hipEventDestroy(e);
+        }
+        for (rm_feedback &f : ctx->feedback)
+            if (f.block) (void)hipFree(f.block);
+        if (ctx->d_scene) (void)hipFree(ctx->d_scene);
+        if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+        if (ctx->d_backproject) (void)hipFree(ctx->d_backproject);
+        if (ctx->d_max) (void)hipFree(ctx->d_max);
+        if (ctx->d_rgb8) (void)hipFree(ctx->d_rgb8);
+        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
-    for (rm_feedback &f : ctx->feedback)
-        if (f.block) (void)hipFree(f.block);
-    if (ctx->d_scene) (void)hipFree(ctx->d_scene);
-    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
-    if (ctx->d_backproject) (void)hipFree(ctx->d_backproject);
-    if (ctx->d_max) (void)hipFree(ctx->d_max);
-    if (ctx->d_rgb8) (void)hipFree(ctx->d_rgb8);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -353,30 +379,36 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
 
     // The reference's hosts hand the whole Scene to every render() call (main.rs:331-333).  A
     // description byte-identical to the one the resident image was built from (cameras apart:
-    // the camera travels as a kernel argument) needs no work at all: two independent 64-bit
-    // digests over every array decide, before anything is rebuilt.
+    // the camera travels as a kernel argument) needs no work at all.  Identity is decided on
+    // the bytes themselves -- the context keeps a copy of the arrays it last built from and
+    // compares in place, one pass, no hashing: a digest can collide, and a collision would
+    // silently render the old scene.
     ctx->upload_calls++;
-    uint64_t dig[2] = {0xcbf29ce484222325ull, 0x9E3779B97F4A7C15ull};
-    auto digest = [&](const void *p, size_t bytes, uint64_t tag) {
-        const unsigned char *b = (const unsigned char *)p;
-        dig[0] = (dig[0] ^ tag ^ bytes) * 0x100000001b3ull;
-        dig[1] = (dig[1] + tag * 0xff51afd7ed558ccdull + bytes) * 0xc4ceb9fe1a85ec53ull;
-        size_t i = 0;
-        for (; i + 8 <= bytes; i += 8) {
-            uint64_t w;
-            std::memcpy(&w, b + i, 8);
-            dig[0] = (dig[0] ^ w) * 0x100000001b3ull;
-            dig[1] = ((dig[1] << 7 | dig[1] >> 57) + w) * 0x9E3779B97F4A7C15ull;
+    const struct { const void *p; size_t bytes; } parts[6] = {
+        {d->shapes, (size_t)d->n_shapes * sizeof(rm_shape_ref)},   {d->spheres, (size_t)d->n_spheres * sizeof(rm_sphere)},
+        {d->polygons, (size_t)d->n_polygons * sizeof(rm_polygon)}, {d->polygon_vertices, (size_t)d->n_polygon_vertices * sizeof(rm_vec3)},
+        {d->triangles, (size_t)d->n_triangles * sizeof(rm_triangle)}, {d->lights, (size_t)d->n_lights * sizeof(rm_light)}};
+    auto same_description = [&]() {
+        size_t off = 0;
+        for (int i = 0; i < 6; i++) {
+            if (ctx->desc_sizes[i] != parts[i].bytes) return false;
+            if (parts[i].bytes && std::memcmp(ctx->desc_bytes.data() + off, parts[i].p, parts[i].bytes) != 0) return false;
+            off += parts[i].bytes;
         }
-        for (; i < bytes; i++) { dig[0] = (dig[0] ^ b[i]) * 0x100000001b3ull; dig[1] = (dig[1] << 5 | dig[1] >> 59) + b[i]; }
+        return true;
     };
-    digest(d->shapes, (size_t)d->n_shapes * sizeof(rm_shape_ref), 1);
-    digest(d->spheres, (size_t)d->n_spheres * sizeof(rm_sphere), 2);
-    digest(d->polygons, (size_t)d->n_polygons * sizeof(rm_polygon), 3);
-    digest(d->polygon_vertices, (size_t)d->n_polygon_vertices * sizeof(rm_vec3), 4);
-    digest(d->triangles, (size_t)d->n_triangles * sizeof(rm_triangle), 5);
-    digest(d->lights, (size_t)d->n_lights * sizeof(rm_light), 6);
-    if (ctx->have_scene && dig[0] == ctx->desc_digest[0] && dig[1] == ctx->desc_digest[1]) {
+    auto keep_description = [&]() {
+        size_t total = 0;
+        for (int i = 0; i < 6; i++) total += parts[i].bytes;
+        ctx->desc_bytes.resize(total);
+        size_t off = 0;
+        for (int i = 0; i < 6; i++) {
+            if (parts[i].bytes) std::memcpy(ctx->desc_bytes.data() + off, parts[i].p, parts[i].bytes);
+            ctx->desc_sizes[i] = parts[i].bytes;
+            off += parts[i].bytes;
+        }
+    };
+    if (ctx->have_scene && same_description()) {
         ctx->camera = d->camera;
         return RM_OK;
     }
@@ -645,7 +677,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     // (a different description that builds the same device image -- an edit undone -- is not copied either)
     if (ctx->have_scene && blob == ctx->host_blob && std::memcmp(&H, &ctx->H, sizeof H) == 0) {
         ctx->camera = d->camera;
-        ctx->desc_digest[0] = dig[0]; ctx->desc_digest[1] = dig[1];
+        keep_description();
         return RM_OK;
     }
     RM_HIP(ctx, hipSetDevice(ctx->device));
@@ -670,7 +702,7 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     }
     ctx->integer_exponents = int_exp;
     ctx->host_blob.swap(blob);
-    ctx->desc_digest[0] = dig[0]; ctx->desc_digest[1] = dig[1];
+    keep_description();
     return RM_OK;
 }
 
@@ -819,12 +851,8 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     // RM_FEEDBACK=1 forces it for every launch of a kernel with the hierarchy walk, =0 switches it off.
     k->feedback = k->bvh && ctx->feedback_mode != 0 && !ctx->debug_empty &&
                   (ctx->feedback_mode == 1 || (p->max_depth >= 6u && tiles >= RM_FEEDBACK_MIN_TILES));
-    k->fn = !k->staged && k->bvh && k->feedback
-                       ? (k->edges ? pick_kernel<1, false, true, true, true, true>(st, pw, f) : pick_kernel<1, false, true, true, false, true>(st, pw, f))
-          : !k->staged ? (k->bvh ? (k->edges ? pick_kernel<1, false, true, true, true>(st, pw, f) : pick_kernel<1, false, true, true, false>(st, pw, f))
-                                 : (k->edges ? pick_kernel<1, false, false, true, true>(st, pw, f) : pick_kernel<1, false, false, true, false>(st, pw, f)))
-          : k->cull    ? (k->edges ? pick_kernel<1, true, false, true, true>(st, pw, f) : pick_kernel<1, true, false, true, false>(st, pw, f))
-                       : pick_kernel<1, true, false, false, false>(st, pw, f);
+    k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->feedback, st, pw);
+    if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
     return RM_OK;
 }
 
@@ -988,15 +1016,12 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
         ctx->frame_h = params->frame_height;
     }
 
-    // Device -> host overlapped with the render: the owned rows are rendered as a few launches
-    // (sub-bands of consecutive patch rows, bottom of the image first: those rows are the
-    // expensive ones), and while launch k+1 runs the rows of launch k cross the PCIe link.
-    // One launch for small frames and for strided bands (rows of several GPUs interleaved).
-    // One launch, then one copy.  The copy IS the call: 48.7 MB of f64 at 1080p take 0.87-0.93 ms
-    // at the 52-56 GB/s this PCIe link delivers device -> host, the kernel 0.09 ms.  Rendering
+    // One launch, then the copy.  The copy IS the call: 48.7 MB of f64 at 1080p take 0.87-0.93 ms
+    // at the 52-56 GB/s this PCIe link delivers device -> host, the kernel 0.08 ms.  Rendering
     // in sub-bands and copying each while the next renders was measured and dropped
-    // (profiles/r02_host_copy.txt): four synchronous copies into pageable memory 0.984 ms, eight
-    // asynchronous ones into page-locked memory 1.04 ms, against 0.985 / 0.973 ms for this.
+    // (profiles/r02_host_copy.txt: 0.97-1.04 ms either way).  What does help is not sending the
+    // black patches (rm_hostio.inc): frames of 2 MB and more take that path, into flat memory as
+    // into rows of rows; smaller ones are copied as they are.
     const size_t row_bytes = (size_t)params->frame_width * 3u * sizeof(double);
     const uint32_t n_rows = band.count();
     RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -1005,7 +1030,14 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     double d2h_ms = 0.;
-    if (host_rgb && n_rows > 0) {
+    if (host_rgb && n_rows > 0 && hostio_packs(ctx, (size_t)n_rows * 32u * row_bytes)) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<double *> rows(params->frame_height);
+        for (uint32_t y = 0; y < params->frame_height; y++) rows[y] = host_rgb + (size_t)y * params->frame_width * 3u;
+        st = hostio_frame_to_rows(ctx, band, params->frame_width, rows.data());
+        if (st != RM_OK) return st;
+        d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else if (host_rgb && n_rows > 0) {
         // Only the owned rows are copied: rows below the last whole patch row keep the
         // caller's previous contents, as in the reference (renderer.rs:53).
         RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1104,3 +1136,4 @@ rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, 
 }  // extern "C"
 
 #include "rm_exchange.inc"
+#include "rm_hostio.inc"

@@ -17,71 +17,10 @@
 
 #include <hip/hip_runtime.h>
 
-#include "rm_internal.h"
-
-#define RM_BVH_NODE_WORDS 16u
-
-// waves per SIMD the integer-power kernels are compiled for (register budget 512 / this)
-#ifndef RM_MIN_WAVES
-#define RM_MIN_WAVES 4
-#endif
+#include "rm_kernel_args.hpp"
 
 namespace rmdev {
 
-// specular power flavours (see specular_pow in rm_trace.inc)
-enum { POW_GENERIC = 0, POW_INTEGER = 1 };
-
-
-// Tile shape (pixels).  RM_TILE_W x (64 / RM_TILE_W): 16x4 makes every tile row 384
-// bytes = three whole 128-byte lines owned by one wave (8x8 rows are 192 bytes and
-// share lines between waves: measured HBM write traffic 1.84x the frame's bytes).
-#ifndef RM_TILE_W
-#define RM_TILE_W 16
-#endif
-constexpr uint32_t TILE_W = RM_TILE_W, TILE_H = 64u / RM_TILE_W;
-static_assert(TILE_W == 8 || TILE_W == 16 || TILE_W == 32, "tile width");
-
-struct KernelArgs {
-    rm_dev_header H;
-    double half_fov, height, width, ratio;   // Renderer (renderer.rs:17-23)
-    double cam_x, cam_y, cam_z;              // Scene.camera
-    double bg_x, bg_y, bg_z;                 // renderer.rs:40-44
-    uint32_t frame_width;                    // FrameBuffer.width
-    uint32_t patch_row_begin;                // first owned patch row
-    uint32_t patch_row_stride;               // owned rows: begin, begin + stride, ...
-    uint32_t u8_compact;                     // RM_FLAG_U8_COMPACT: frame8 holds only the owned rows, packed
-    uint32_t max_depth;                      // renderer.rs:262
-    uint32_t n_width;                        // patches per row, renderer.rs:54
-    uint32_t n_tiles;                        // 16 * patches in the band
-    uint32_t order_mul;                      // dispatch order: tile = (id * order_mul + order_add) % n_tiles
-    uint32_t order_add;
-    uint32_t f64_compact;                    // RM_FLAG_F64_COMPACT: frame holds only the owned rows, packed
-    double cull_cos;                         // bundles at least this narrow cull primitives (> 1: never; RM_DISABLE_CULL)
-    uint8_t *frame8;                         // optional [H][W][3] u8 display frame (NULL: not written)
-    // backproject (renderer.rs:128-135) tabulated per column and per row by the host with the
-    // kernel's own operations: bp_x[x] = 2 (x / width - 0.5) half_fov ratio, bp_y[y] = -2 (y / height - 0.5) half_fov
-    const double *bp_x, *bp_y;
-    unsigned long long *debug_stamps;        // RM_EXP_STAMPS diagnostic build only
-    // Frame-to-frame feedback (rm_device.hip, rm_feedback): the tiles that took longest in the
-    // previous frame on this stream are dispatched first.  fb_flag == NULL: off.
-    const uint32_t *fb_list;                 // previous frame: its long tiles, fb_count[0] of them (at most fb_cap)
-    const uint32_t *fb_count;
-    const uint8_t *fb_flag;                  // previous frame: 1 per tile that is on the list
-    const uint32_t *fb_hist;                 // previous frame: its tiles by time, RM_FB_BUCKETS buckets (sampled)
-    uint32_t *fb_next_list, *fb_next_count, *fb_next_hist;   // what this frame leaves for the next
-    uint8_t *fb_next_flag;
-    uint32_t *fb_zero;                       // counter and histogram of the frame after next: cleared by this one
-    uint32_t *fb_threshold;                  // ticks from which a tile is long: set by this frame's first wave
-    uint32_t fb_cap;                         // workgroups [0, fb_cap) take the list, the rest the tiles in order
-    uint32_t fb_long_ticks;                  // the threshold while there is no histogram (100 MHz ticks)
-    uint32_t fb_target;                      // tiles the list should hold (0: fb_long_ticks is the threshold)
-};
-
-// Feedback histogram: tile times in 100 MHz ticks, four buckets per octave (bucket b holds
-// [edge(b), edge(b+1)), edge(b) = (4 + b % 4) << (b / 4) >> 2: 1, 1, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7, 8, 10, ...);
-// every RM_FB_SAMPLE-th tile is counted.
-#define RM_FB_BUCKETS 64u
-#define RM_FB_SAMPLE 8u
 __device__ __forceinline__ uint32_t fb_bucket(uint32_t ticks) {
     const uint32_t t = ticks < 4u ? 4u : ticks;
     const uint32_t e = 31u - (uint32_t)__builtin_clz(t);            // t in [2^e, 2^(e+1)), e >= 2
@@ -94,23 +33,6 @@ __device__ __forceinline__ uint32_t fb_edge(uint32_t b) { return (4u + (b & 3u))
 // (a real move: an empty asm with a tied operand is coalesced back into the tuple)
 __device__ __forceinline__ double own_sgpr(double v) { double r; asm("s_mov_b64 %0, %1" : "=s"(r) : "s"(v)); return r; }
 __device__ __forceinline__ uint32_t own_sgpr(uint32_t v) { uint32_t r; asm("s_mov_b32 %0, %1" : "=s"(r) : "s"(v)); return r; }
-
-struct StackEntry {
-    double ox, oy, oz, dx, dy, dz, w;
-    uint32_t depth, _pad;
-};
-
-// Per-wave LDS block behind the scene copy (8-byte words):
-//   [0, 448)    level 0 of the lanes' ray stacks: 7 f64 fields, one lane-contiguous column each
-//   [448, 480)  its u32 depth column
-//   [480, 512)  the wave's hierarchy stack: 64 u32 entries
-//   [512, 704)  the tile's pixel sums, [pixel][channel] -- read as they lie by the store phase
-//   [704, 736)  pairing table of the ray hand-over: 64 u32 entries
-#define RM_WAVE_L0_DEPTH_WORDS 448u
-#define RM_WAVE_BVH_STACK_WORDS 480u
-#define RM_WAVE_SUM_WORDS 512u
-#define RM_WAVE_PAIR_WORDS 704u
-#define RM_WAVE_LDS_WORDS 736u
 
 extern __shared__ double rm_lds[];
 
@@ -153,6 +75,7 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, 
 }  // namespace rmdev
 
 // ---- the two numeric flavours of the same source --------------------------------------
+#if !defined(RM_KERNEL_FAST) || !RM_KERNEL_FAST
 #define RM_FLAVOR_NS rmdev_strict
 #define RM_FAST 0
 #pragma clang fp contract(off)
@@ -160,7 +83,9 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, 
 #include "rm_render_kernel.inc"
 #undef RM_FLAVOR_NS
 #undef RM_FAST
+#endif
 
+#if !defined(RM_KERNEL_FAST) || RM_KERNEL_FAST
 #define RM_FLAVOR_NS rmdev_fast
 #define RM_FAST 1
 #pragma clang fp contract(fast)
@@ -169,5 +94,6 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, 
 #undef RM_FLAVOR_NS
 #undef RM_FAST
 #pragma clang fp contract(off)
+#endif
 
 #endif

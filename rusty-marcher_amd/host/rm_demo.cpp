@@ -3,7 +3,12 @@
 // written against the C++ host mirror (rusty_marcher.hpp).  Native harness for the C ABI.
 //
 //   rm_demo [--obj FILE] [--width W] [--height H] [--fov F] [--depth D] [--frames N]
-//           [--camera x,y,z] [--fast-fp] [--no-normalize] [--out FILE.ppm] [--dump-scene]
+//           [--camera x,y,z] [--fast-fp] [--no-normalize] [--device-frame] [--out FILE.ppm] [--dump-scene]
+//
+// Default: render() fills a FrameBuffer of rows of rows (framebuffer.rs:6-22) and the host
+// normalises and quantises it, as save_to_file does (main.rs:353-357).  --device-frame: the f64
+// frame stays on the device, render() brings back only fb.to_vec() (what the window blits) and the
+// saved file comes from the device post-process.
 //
 // Defaults reproduce the reference's committed engine/out.ppm: 800x600, fov 1.5, depth 3.
 #include <cstdio>
@@ -43,7 +48,7 @@ int main(int argc, char **argv) {
     size_t width = 800, height = 600;
     double fov = 1.5;
     unsigned depth = 3, frames = 1;
-    bool fast = false, normalize = true, dump = false;
+    bool fast = false, normalize = true, dump = false, device_frame = false;
     Vec3f cam_off;
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
@@ -56,9 +61,10 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--camera")) { if (std::sscanf(next(), "%lf,%lf,%lf", &cam_off.x, &cam_off.y, &cam_off.z) != 3) return 2; }
         else if (!std::strcmp(argv[i], "--fast-fp")) fast = true;
         else if (!std::strcmp(argv[i], "--no-normalize")) normalize = false;
+        else if (!std::strcmp(argv[i], "--device-frame")) device_frame = true;
         else if (!std::strcmp(argv[i], "--out")) out = next();
         else if (!std::strcmp(argv[i], "--dump-scene")) dump = true;
-        else { std::fprintf(stderr, "usage: rm_demo [--obj FILE] [--width W] [--height H] [--fov F] [--depth D] [--frames N] [--camera x,y,z] [--fast-fp] [--no-normalize] [--out FILE.ppm] [--dump-scene]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rm_demo [--obj FILE] [--width W] [--height H] [--fov F] [--depth D] [--frames N] [--camera x,y,z] [--fast-fp] [--no-normalize] [--device-frame] [--out FILE.ppm] [--dump-scene]\n"); return 2; }
     }
     try {
         // main.rs:119-123 (default scene) / main.rs:261-327 (open .obj)
@@ -71,16 +77,25 @@ int main(int argc, char **argv) {
         r.max_depth = depth;
         if (fast) r.flags |= RM_FLAG_FAST_FP;
         std::string msg;
-        for (unsigned f = 0; f < frames; f++) msg = r.render(fb, sc);        // main.rs:329-333: the whole Scene goes in every time
+        std::vector<uint8_t> display;
+        for (unsigned f = 0; f < frames; f++)                                // main.rs:329-333: the whole Scene goes in every time
+            msg = device_frame ? r.render_display(fb.width, fb.height, sc, display) : r.render(fb, sc);
         std::printf("kernel %.3f ms, device->host %.3f ms, call %.3f ms\n", r.last_timing.kernel_ms, r.last_timing.d2h_ms,
                     r.last_timing.total_ms);
-        uint64_t up_calls = 0, up_copies = 0;
+        uint64_t up_calls = 0, up_copies = 0, bytes = 0, patches = 0, sent = 0;
         check(rm_scene_uploads(r.context(), &up_calls, &up_copies), r.context());
         std::printf("scene uploads: %llu calls, %llu copies to the device\n", (unsigned long long)up_calls,
                     (unsigned long long)up_copies);
+        check(rm_hostio_stats(r.context(), &bytes, &patches, &sent, nullptr), r.context());
+        std::printf("last frame: %llu bytes over the link, %llu of %llu patches sent\n", (unsigned long long)bytes,
+                    (unsigned long long)sent, (unsigned long long)patches);
         // main.rs:353-357 save_to_file: fb.normalize(); fb.write_ppm("out.ppm")
-        const std::vector<uint8_t> rgb = renderer::to_vec(r, fb, normalize);
-        renderer::write_ppm(out, fb, rgb);
+        if (device_frame) {
+            renderer::write_ppm(out, fb.width, fb.height, renderer::to_vec_on_device(r, fb.width, fb.height, normalize));
+        } else {
+            if (normalize) fb.normalize();
+            fb.write_ppm(out);
+        }
         std::printf("Saved rendered file %s\n", out.c_str());
     } catch (const Panic &p) {
         std::fprintf(stderr, "panic: %s (status %d)\n", p.what(), (int)p.status);

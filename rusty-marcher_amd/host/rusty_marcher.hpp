@@ -237,12 +237,52 @@ struct Scene {
 
 // ---- framebuffer.rs ---------------------------------------------------------------------
 namespace framebuffer {
+// framebuffer.rs:6-10: `buffer: Vec<Vec<geometry::Vec3f>>` -- one heap allocation per scan line.
+// Vec3f is three doubles, x y z in that order (the `#[repr(C)]` the shim asks of geometry.rs:4-8).
+static_assert(sizeof(Vec3f) == 3 * sizeof(double), "Vec3f must be three packed doubles");
 struct FrameBuffer {
     size_t width, height;
-    std::vector<double> buffer;   // [height][width][3] row-major (the reference keeps one Vec per row)
+    std::vector<std::vector<Vec3f>> buffer;   // [height] rows of [width] pixels
+    // what rm_render_rows / rm_fetch_rows take: one pointer per scan line
+    std::vector<double *> row_pointers() {
+        std::vector<double *> rows(height);
+        for (size_t y = 0; y < height; y++) rows[y] = reinterpret_cast<double *>(buffer[y].data());
+        return rows;
+    }
+    static uint8_t quantize(double f) {                                   // framebuffer.rs:80-82
+        const double c = f > 0. ? (f < 1. ? f : 1.) : 0.;                 // f.max(0.).min(1.): NaN -> 0
+        return (uint8_t)(255. * c);
+    }
+    std::vector<uint8_t> to_vec() const {                                 // framebuffer.rs:40-55
+        std::vector<uint8_t> out(width * height * 3);
+        size_t k = 0;
+        for (size_t i = 0; i < height; i++)
+            for (size_t j = 0; j < width; j++) {
+                out[k++] = quantize(buffer[i][j].x); out[k++] = quantize(buffer[i][j].y); out[k++] = quantize(buffer[i][j].z);
+            }
+        return out;
+    }
+    void normalize() {                                                    // framebuffer.rs:58-77
+        double mx = 0., my = 0., mz = 0.;
+        auto fmax = [](double a, double b) { return b > a ? b : a; };     // f64::max: NaN loses
+        for (const auto &row : buffer)
+            for (const Vec3f &p : row) { mx = fmax(mx, p.x); my = fmax(my, p.y); mz = fmax(mz, p.z); }
+        const double max_val = fmax(fmax(mx, my), mz);
+        if (max_val > 0.) {
+            const double s = 1. / max_val;
+            for (auto &row : buffer)
+                for (Vec3f &p : row) p = p.scaled(s);
+        }
+    }
+    void write_ppm(const std::string &filename) const {                   // framebuffer.rs:26-38
+        std::ofstream f(filename, std::ios::binary);
+        f << "P6\n" << width << " " << height << "\n255\n";
+        const std::vector<uint8_t> rgb = to_vec();
+        f.write(reinterpret_cast<const char *>(rgb.data()), (std::streamsize)rgb.size());
+    }
 };
 inline FrameBuffer create_frame_buffer(size_t width, size_t height) {     // framebuffer.rs:12-22
-    return FrameBuffer{width, height, std::vector<double>(width * height * 3, 0.)};
+    return FrameBuffer{width, height, std::vector<std::vector<Vec3f>>(height, std::vector<Vec3f>(width, Vec3f::zero()))};
 }
 }  // namespace framebuffer
 
@@ -264,13 +304,38 @@ struct Renderer {
         fov = p.fov; half_fov = p.half_fov; height = p.height; width = p.width; ratio = p.ratio;
     }
 
-    // renderer.rs:36-126: synchronous, fills `frame`, returns the status string
+    // renderer.rs:36-126: synchronous, fills `frame` -- rows of rows, like the reference's -- and
+    // returns the status string
     std::string render(framebuffer::FrameBuffer &frame, const scene::Scene &sc) {
         const auto t0 = std::chrono::steady_clock::now();
+        const rm_params p = prepare(frame.width, frame.height, sc);
+        std::vector<double *> rows = frame.row_pointers();
+        check(rm_render_rows(ctx_, &p, rows.data(), &last_timing), ctx_);
+        return status(t0, frame.width, frame.height);
+    }
+    // The same call with a device-resident FrameBuffer: the f64 frame stays on the device, what
+    // comes back is `fb.to_vec()` -- the bytes the window blits (main.rs:337-346) -- into `rgb8`
+    // (width * height * 3; rows below the last whole patch row keep their contents).
+    std::string render_display(size_t width, size_t height, const scene::Scene &sc, std::vector<uint8_t> &rgb8) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const rm_params p = prepare(width, height, sc);
+        rgb8.resize(width * height * 3);
+        check(rm_render_display(ctx_, &p, rgb8.data(), &last_timing), ctx_);
+        return status(t0, width, height);
+    }
+    // f64 rows of the device-resident frame on demand (save_to_file: normalize + write_ppm)
+    void fetch(framebuffer::FrameBuffer &frame) {
+        std::vector<double *> rows = frame.row_pointers();
+        check(rm_fetch_rows(context(), rows.data(), 0, 0), ctx_);
+    }
+    rm_ctx *context() { if (!ctx_) check(rm_init(0, &ctx_)); return ctx_; }
+
+  private:
+    rm_ctx *ctx_ = nullptr;
+    rm_params prepare(size_t width_px, size_t height_px, const scene::Scene &sc) {
         if (!ctx_) check(rm_init(0, &ctx_));
-        if (frame.height % 32 != 0 || frame.width % 32 != 0) std::printf("Dimensions mismatch\n");
-        std::printf("Rendering using patches of size %d, using %zu patches overall\n", 32,
-                    (frame.height / 32) * (frame.width / 32));
+        if (height_px % 32 != 0 || width_px % 32 != 0) std::printf("Dimensions mismatch\n");
+        std::printf("Rendering using patches of size %d, using %zu patches overall\n", 32, (height_px / 32) * (width_px / 32));
         bool owned = false;
         rm_scene *flat = sc.flatten(&owned);
         rm_scene_desc d;
@@ -280,38 +345,37 @@ struct Renderer {
         check(up, ctx_);
         rm_params p;
         rm_create_renderer(fov, height, width, &p);
-        p.frame_width = (uint32_t)frame.width;
-        p.frame_height = (uint32_t)frame.height;
+        p.frame_width = (uint32_t)width_px;
+        p.frame_height = (uint32_t)height_px;
         p.max_depth = max_depth;
         p.flags = flags;
-        check(rm_render(ctx_, &p, frame.buffer.data(), &last_timing), ctx_);
+        return p;
+    }
+    static std::string status(std::chrono::steady_clock::time_point t0, size_t width_px, size_t height_px) {
         const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(
                                 std::chrono::steady_clock::now() - t0).count();
         char buf[256];
-        rm_format_status(buf, sizeof buf, ms, (uint32_t)frame.width, (uint32_t)frame.height);
+        rm_format_status(buf, sizeof buf, ms, (uint32_t)width_px, (uint32_t)height_px);
         std::printf("%s\n", buf);
         return buf;
     }
-    rm_ctx *context() { if (!ctx_) check(rm_init(0, &ctx_)); return ctx_; }
-
-  private:
-    rm_ctx *ctx_ = nullptr;
 };
 inline Renderer create_renderer(double fov, double height, double width) {   // renderer.rs:25-33: (fov, height, width)
     return Renderer(fov, height, width);
 }
 
-// FrameBuffer::normalize + to_vec + write_ppm (framebuffer.rs:26-82) on the frame the
-// renderer's context holds on the device; also refreshes `frame` when normalising.
-inline std::vector<uint8_t> to_vec(Renderer &r, framebuffer::FrameBuffer &frame, bool normalize) {
-    std::vector<uint8_t> out(frame.width * frame.height * 3);
-    check(rm_postprocess(r.context(), nullptr, (uint32_t)frame.width, (uint32_t)frame.height, normalize ? 1 : 0,
-                         out.data(), nullptr), r.context());
+// FrameBuffer::normalize + to_vec (framebuffer.rs:40-77) run on the frame the renderer's context
+// holds on the device (rm_postprocess): what save_to_file needs when the f64 frame was never
+// fetched.  `frame` gives the size.
+inline std::vector<uint8_t> to_vec_on_device(Renderer &r, size_t width, size_t height, bool normalize) {
+    std::vector<uint8_t> out(width * height * 3);
+    check(rm_postprocess(r.context(), nullptr, (uint32_t)width, (uint32_t)height, normalize ? 1 : 0, out.data(), nullptr),
+          r.context());
     return out;
 }
-inline void write_ppm(const std::string &filename, const framebuffer::FrameBuffer &frame, const std::vector<uint8_t> &rgb) {
+inline void write_ppm(const std::string &filename, size_t width, size_t height, const std::vector<uint8_t> &rgb) {
     std::ofstream f(filename, std::ios::binary);
-    f << "P6\n" << frame.width << " " << frame.height << "\n255\n";
+    f << "P6\n" << width << " " << height << "\n255\n";
     f.write(reinterpret_cast<const char *>(rgb.data()), (std::streamsize)rgb.size());
 }
 }  // namespace renderer

@@ -139,6 +139,10 @@ extern "C" {
     fn rm_scene_uploads(ctx: *mut RmCtx, calls: *mut u64, copies: *mut u64) -> c_int;
     fn rm_camera_update(ctx: *mut RmCtx, camera: RmVec3) -> c_int;
     fn rm_render(ctx: *mut RmCtx, params: *const RmParams, host_rgb: *mut f64, timing: *mut RmTiming) -> c_int;
+    fn rm_render_rows(ctx: *mut RmCtx, params: *const RmParams, rows: *const *mut f64, timing: *mut RmTiming) -> c_int;
+    fn rm_render_display(ctx: *mut RmCtx, params: *const RmParams, host_rgb8: *mut u8, timing: *mut RmTiming) -> c_int;
+    fn rm_fetch_rows(ctx: *mut RmCtx, rows: *const *mut f64, patch_row_begin: u32, patch_row_end: u32) -> c_int;
+    fn rm_hostio_stats(ctx: *mut RmCtx, bytes_copied: *mut u64, patches: *mut u64, patches_sent: *mut u64, threads: *mut c_int) -> c_int;
     fn rm_render_device(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, hip_stream: *mut c_void) -> c_int;
     fn rm_render_device_u8(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_rgb8: *mut c_void, hip_stream: *mut c_void) -> c_int;
     fn rm_device_framebuffer(ctx: *mut RmCtx, device_rgb: *mut *mut c_void, bytes: *mut usize) -> c_int;
@@ -209,41 +213,34 @@ impl SceneSink {
     }
 }
 
-/// One GPU: context + a page-locked staging frame (rm_host_alloc).  Owned by `Renderer`
-/// (renderer.rs:17-23 gains a `gpu: RefCell<Gpu>` field) or by `Win`.
+/// One GPU.  Owned by `Renderer` (renderer.rs:17-23 gains a `gpu: RefCell<Gpu>` field) or by
+/// `Win`.  The page-locked staging frame the copies go through belongs to the library's context
+/// (include/rusty_marcher_amd.h, rm_render_rows): nothing to allocate, grow or free here.
 pub struct Gpu {
     ctx: *mut RmCtx,
-    staging: *mut f64,
-    staging_len: usize,
+}
+
+/// `FrameBuffer.buffer` is `Vec<Vec<Vec3f>>` (framebuffer.rs:6-10): one heap allocation per scan
+/// line.  With `#[repr(C)]` on `Vec3f` (geometry.rs:4-8: three f64, x y z -- INTEGRATION.md
+/// section 3d, the fourth one-line patch) a row is `width * 3` doubles and the library fills the
+/// rows in place.
+fn row_pointers(frame: &mut FrameBuffer) -> Vec<*mut f64> {
+    frame.buffer.iter_mut().map(|row| row.as_mut_ptr() as *mut f64).collect()
 }
 
 impl Gpu {
     pub fn new(device: i32) -> Gpu {
         let mut ctx: *mut RmCtx = ptr::null_mut();
         check(unsafe { rm_init(device, &mut ctx) }, ptr::null());
-        Gpu { ctx, staging: ptr::null_mut(), staging_len: 0 }
+        Gpu { ctx }
     }
 
-    /// Body of `Renderer::render` (renderer.rs:36-126) with the Rayon loop and the
-    /// serial scatter replaced by one library call.
-    pub fn render(
-        &mut self,
-        fov: f64,
-        height: f64,
-        width: f64,
-        frame: &mut FrameBuffer,
-        scene: &::scene::Scene,
-    ) -> String {
-        let now = ::std::time::Instant::now();
-        if (frame.height % 32 != 0) || (frame.width % 32 != 0) {
-            println!("Dimensions mismatch") // renderer.rs:49-51
-        }
-
-        // flatten Scene -> rm_scene (shapes in list order: ties, shapes.rs:130).  render() gets
-        // the whole Scene every call (main.rs:331-333), so the flat copy is rebuilt every call
-        // (microseconds for the reference's scenes); rm_scene_upload recognises a scene whose
-        // device image is already resident and copies nothing -- camera moves included, the
-        // camera is a kernel argument.
+    /// flatten Scene -> rm_scene (shapes in list order: ties, shapes.rs:130) and hand it to the
+    /// context.  render() gets the whole Scene every call (main.rs:331-333), so the flat copy is
+    /// rebuilt every call (microseconds for the reference's scenes); rm_scene_upload compares
+    /// it with the description the resident device image was built from and copies nothing when
+    /// they are the same -- camera moves included, the camera is a kernel argument.
+    fn upload(&mut self, scene: &::scene::Scene) {
         let mut raw: *mut RmScene = ptr::null_mut();
         check(unsafe { rm_scene_new(&mut raw) }, ptr::null());
         {
@@ -259,60 +256,87 @@ impl Gpu {
         check(unsafe { rm_scene_set_camera(raw, scene.camera.into()) }, ptr::null());
         let mut desc: RmSceneDesc = unsafe { ::std::mem::zeroed() };
         check(unsafe { rm_scene_get_desc(raw, &mut desc) }, ptr::null());
-        check(unsafe { rm_scene_upload(self.ctx, &desc) }, self.ctx);
+        let st = unsafe { rm_scene_upload(self.ctx, &desc) };
         unsafe { rm_scene_free(raw) };
+        check(st, self.ctx);
+    }
 
+    fn params(fov: f64, height: f64, width: f64, frame_width: usize, frame_height: usize) -> RmParams {
+        if (frame_height % 32 != 0) || (frame_width % 32 != 0) {
+            println!("Dimensions mismatch") // renderer.rs:49-51
+        }
         let mut p: RmParams = unsafe { ::std::mem::zeroed() };
         unsafe { rm_create_renderer(fov, height, width, &mut p) };
-        p.frame_width = frame.width as u32; // renderer.rs:53-54 read the FrameBuffer, not the Renderer
-        p.frame_height = frame.height as u32;
+        p.frame_width = frame_width as u32; // renderer.rs:53-54 read the FrameBuffer, not the Renderer
+        p.frame_height = frame_height as u32;
         p.max_depth = 3; // renderer.rs:262
+        p
+    }
 
-        // FrameBuffer.buffer is Vec<Vec<Vec3f>>: one allocation per row (framebuffer.rs:12-22),
-        // and Vec3f is not #[repr(C)]: render into a flat page-locked staging frame, then copy
-        // the RENDERED rows back.  rm_render writes whole patch rows only, so the rows below the
-        // last whole patch row keep their previous contents without being staged at all
-        // (renderer.rs:53).
-        let n = frame.width * frame.height * 3;
-        if n > self.staging_len {
-            if !self.staging.is_null() {
-                unsafe { rm_host_free(self.ctx, self.staging as *mut c_void) };
-            }
-            let mut mem: *mut c_void = ptr::null_mut();
-            check(unsafe { rm_host_alloc(self.ctx, n * 8, &mut mem) }, self.ctx);
-            self.staging = mem as *mut f64;
-            self.staging_len = n;
-        }
-        let mut timing = RmTiming::default();
-        check(unsafe { rm_render(self.ctx, &p, self.staging, &mut timing) }, self.ctx);
-        let rendered_rows = (frame.height / 32) * 32;
-        let staged = unsafe { ::std::slice::from_raw_parts(self.staging, n) };
-        for (j, row) in frame.buffer.iter_mut().enumerate().take(rendered_rows) {
-            for (i, px) in row.iter_mut().enumerate() {
-                let k = (j * frame.width + i) * 3;
-                px.x = staged[k];
-                px.y = staged[k + 1];
-                px.z = staged[k + 2];
-            }
-        }
-
+    fn status(now: ::std::time::Instant, frame_width: usize, frame_height: usize) -> String {
         // renderer.rs:111-125
         let ms = now.elapsed().as_secs() * 1_000 + u64::from(now.elapsed().subsec_nanos()) / 1_000_000;
         let mut buf = [0 as c_char; 256];
-        unsafe { rm_format_status(buf.as_mut_ptr(), buf.len(), ms, frame.width as u32, frame.height as u32) };
+        unsafe { rm_format_status(buf.as_mut_ptr(), buf.len(), ms, frame_width as u32, frame_height as u32) };
         let message = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
         println!("{}", message);
         message
+    }
+
+    /// Body of `Renderer::render` (renderer.rs:36-126) with the Rayon loop and the serial
+    /// scatter replaced by one library call that fills `frame.buffer`'s rows in place.  The rows
+    /// below the last whole patch row keep their previous contents (renderer.rs:53): the library
+    /// never touches them.
+    pub fn render(
+        &mut self,
+        fov: f64,
+        height: f64,
+        width: f64,
+        frame: &mut FrameBuffer,
+        scene: &::scene::Scene,
+    ) -> String {
+        let now = ::std::time::Instant::now();
+        self.upload(scene);
+        let p = Gpu::params(fov, height, width, frame.width, frame.height);
+        let rows = row_pointers(frame);
+        let mut timing = RmTiming::default();
+        check(unsafe { rm_render_rows(self.ctx, &p, rows.as_ptr(), &mut timing) }, self.ctx);
+        Gpu::status(now, frame.width, frame.height)
+    }
+
+    /// `render` with a device-resident FrameBuffer: the f64 frame stays on the GPU and only
+    /// `fb.to_vec()` comes back -- what update_raytrace_image hands to the pixbuf
+    /// (main.rs:337-346).  `display` is resized to width * height * 3; bytes of rows below the
+    /// last whole patch row keep their contents.  `fetch` brings the f64 rows over when
+    /// save_to_file wants them (main.rs:353-357).
+    pub fn render_display(
+        &mut self,
+        fov: f64,
+        height: f64,
+        width: f64,
+        frame_width: usize,
+        frame_height: usize,
+        scene: &::scene::Scene,
+        display: &mut Vec<u8>,
+    ) -> String {
+        let now = ::std::time::Instant::now();
+        self.upload(scene);
+        let p = Gpu::params(fov, height, width, frame_width, frame_height);
+        display.resize(frame_width * frame_height * 3, 0);
+        let mut timing = RmTiming::default();
+        check(unsafe { rm_render_display(self.ctx, &p, display.as_mut_ptr(), &mut timing) }, self.ctx);
+        Gpu::status(now, frame_width, frame_height)
+    }
+
+    /// The f64 rows of the frame the last render left on the device, into `frame.buffer`.
+    pub fn fetch(&mut self, frame: &mut FrameBuffer) {
+        let rows = row_pointers(frame);
+        check(unsafe { rm_fetch_rows(self.ctx, rows.as_ptr(), 0, 0) }, self.ctx);
     }
 }
 
 impl Drop for Gpu {
     fn drop(&mut self) {
-        unsafe {
-            if !self.staging.is_null() {
-                rm_host_free(self.ctx, self.staging as *mut c_void);
-            }
-            rm_destroy(self.ctx)
-        }
+        unsafe { rm_destroy(self.ctx) }
     }
 }

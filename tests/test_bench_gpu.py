@@ -65,3 +65,73 @@ def test_library_exchange_through_rccl_world_of_one(payload):
         assert d["display_bytes_differing_from_oracle"] == 0
     else:
         assert d["max_abs_delta_vs_oracle"] < 1e-9
+
+
+# ---------------------------------------------------------------- two GPUs and more (self-arming)
+def _gpus():
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.visible_gpus()
+    if n is None:
+        import torch
+        n = torch.cuda.device_count()
+    return n
+
+
+needs_two = pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs: one rank per GPU over real RCCL (runs by itself on a bigger box)")
+
+
+@needs_two
+@pytest.mark.parametrize("payload", ["u8", "f64"])
+@pytest.mark.parametrize("exchange", ["gather", "allgather"])
+def test_two_gpus_over_rccl(payload, exchange):
+    """The replacement of the Rayon workers (renderer.rs:63-89) with one rank per GPU: cyclic patch
+    rows, ONE exchange per frame over RCCL / xGMI -- torch.distributed's and the library's own
+    (rm_frame_submit*: four frames in flight), both checked against the oracle and against each
+    other on a check frame, every wait bounded, the whole run under bench.py's deadline."""
+    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "2", "--check", "--no-sizes", "--payload", payload,
+                "--exchange", exchange, "--deadline", "420"])
+    assert d["n_gpus"] == 2 and d["value"] and d["value"] > 0
+    if payload == "u8":
+        assert d["display_bytes_differing_from_oracle"] == 0
+    else:
+        assert d["max_abs_delta_vs_oracle"] < 1e-9
+    paths = d["exchange_paths"]
+    assert "torch" in paths
+    assert "direct" in paths, d["config"]["collective"]                # the library's exchange completed and agreed
+    assert paths["direct"]["rccl_sees"]["world"] == 2 and paths["direct"]["frames_in_flight"] == 4
+
+
+@needs_two
+def test_rm_walk_two_ranks_match_the_oracle(tmp_path):
+    """rm_walk --world 2: two processes, one GPU each, the unique id through a file, rank 0 writes
+    every frame's display bytes -- the oracle's to_vec() of the same camera position."""
+    import numpy as np
+
+    import __graft_entry__ as G
+    import workloads
+    O = G.load_oracle()
+    exe = os.path.join(G.PKG_DIR, "lib", "rm_walk")
+    w, h, depth, frames = 640, 360, 4, 6
+    common = ["--world", "2", "--frames", str(frames), "--width", str(w), "--height", str(h), "--depth", str(depth),
+              "--step", "0.5,0.25,-1", "--id-file", str(tmp_path / "id.bin"), "--run-id", "test-%d" % os.getpid()]
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", RM_FRAME_TIMEOUT_MS="60000")
+    procs = [subprocess.Popen([exe, "--rank", str(r), "--device", str(r)] + common + (["--out", str(tmp_path / "walk")] if r == 0 else []),
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in (0, 1)]
+    try:
+        outs = [p.communicate(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [0, 0], [o[1].decode()[-1500:] for o in outs]
+    rows = h // 32 * 32
+    so = workloads.oracle_scene(O, "demo")
+    for k in range(frames):
+        data = (tmp_path / ("walk_%04d.ppm" % k)).read_bytes()
+        header = b"P6\n%d %d\n255\n" % (w, rows)
+        assert data.startswith(header)
+        so.set_camera((0.5 * k, 0.25 * k, -1. * k))
+        ref = O.to_vec(O.render(so, w, h, max_depth=depth)[:rows].copy())
+        got = np.frombuffer(data[len(header):], np.uint8)
+        assert int((got != ref).sum()) <= 2, "frame %d" % k

@@ -51,9 +51,34 @@ def test_a_hung_rank_is_killed_at_the_deadline_and_reported():
     assert b"deadline" in p.stderr
 
 
+def test_gpu_count_comes_from_sysfs_not_from_the_runtime(tmp_path):
+    """The launcher counts GPUs from the KFD topology (nodes with SIMDs), honours the
+    *_VISIBLE_DEVICES lists, and never imports torch to do so."""
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.visible_gpus(); "
+            "assert 'torch' not in sys.modules; print(-1 if n is None else n)" % ROOT)
+    e = dict(os.environ)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        e.pop(k, None)
+    n = int(subprocess.check_output([sys.executable, "-c", code], env=e).decode())
+    if os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        assert n >= 0
+        import torch
+        if torch.cuda.is_available():
+            assert n == torch.cuda.device_count()
+        m = int(subprocess.check_output([sys.executable, "-c", code], env=dict(e, HIP_VISIBLE_DEVICES="0")).decode())
+        assert m == min(n, 1)
+    else:
+        assert n == -1
+
+
 def test_without_the_gpus_it_fails_loudly_instead_of_benchmarking_one():
-    import torch
-    if torch.cuda.device_count() >= 2:
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.visible_gpus()
+    if have is None:
+        import torch
+        have = torch.cuda.device_count()
+    if have >= 2:
         import pytest
         pytest.skip("two GPUs are present")
     p, _ = _run(["--gpus", "2", "--steps", "2"])

@@ -59,6 +59,19 @@ def gpu_render(pkg, ctx, scene, w, h, depth, band=None, out=None, fov=workloads.
     return out, t
 
 
+def device_render_with_sentinel(pkg, ctx, scene, w, h, depth, band=None, sentinel=-1.):
+    """One frame into a caller-owned device buffer that holds `sentinel` everywhere beforehand."""
+    import torch
+    ctx.upload(scene.flatten())
+    p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
+    p.flags = _FLAGS["value"]
+    dev = torch.full((h, w, 3), sentinel, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.render_device(p, dev.data_ptr())
+    torch.cuda.synchronize()
+    return dev.cpu().numpy()
+
+
 def compare(gpu, ref, tol=TIGHT):
     d = np.abs(gpu - ref)
     if _FLAGS["value"] & RM_FLAG_FAST_FP:
@@ -118,17 +131,43 @@ def test_config_c4_8k(pkg, O, ctx):
 def test_config_c5_synthetic_bands(pkg, O, ctx):
     """4096x4096, 256 spheres, depth 10: the oracle needs minutes for the full frame,
     so eight patch rows spread over the image are checked pixel for pixel; the rest is
-    covered by the property tests below."""
+    covered by the property tests below.
+    THREE frames on the context's stream, like the frames bench.py times: this launch geometry
+    (262,144 tiles, depth cap 10, hierarchy kernel) carries the frame-to-frame feedback, whose
+    list of long tiles is empty for the first frame and drives the dispatch of the second and
+    third (list first: capacity 32,768, target 16,384; then the tiles in order less the flagged
+    ones).  Each frame goes into a caller-owned device buffer pre-filled with a sentinel, so a
+    tile that was left out -- or rendered into the wrong place -- cannot hide behind the previous
+    frame's pixels; all three must hold the oracle's rows and equal each other bit for bit."""
+    import torch
     c = workloads.CONFIGS["C5"]
     w, h, depth = c["width"], c["height"], c["max_depth"]
-    gpu, _ = gpu_render(pkg, ctx, workloads.product_scene(pkg, "synthetic256"), w, h, depth)
+    ctx.upload(workloads.product_scene(pkg, "synthetic256").flatten())
+    p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    assert ctx.kernel_name(p).rstrip(">").endswith("true"), "C5 is expected to run the kernel with the feedback"
     so = workloads.oracle_scene(O, "synthetic256")
     ref = np.zeros((h, w, 3), dtype=np.float64)
     rows = [0, 23, 47, 64, 77, 96, 111, 127]
     for r in rows:
         O.render(so, w, h, max_depth=depth, frame=ref, band=(r, r + 1))
-        compare(gpu[r * 32:(r + 1) * 32], ref[r * 32:(r + 1) * 32])
-    assert (gpu.sum(axis=2) > 0).mean() > 0.3
+    dev = torch.empty((h, w, 3), dtype=torch.float64, device="cuda:0")
+    first = None
+    for frame_no in range(3):
+        dev.fill_(-1.)
+        torch.cuda.synchronize()
+        ctx.render_device(p, dev.data_ptr())            # (HIP's default stream: the same one every time)
+        torch.cuda.synchronize()
+        gpu = dev.cpu().numpy()
+        assert not (gpu == -1.).any(), "frame %d: pixels never written" % frame_no
+        for r in rows:
+            compare(gpu[r * 32:(r + 1) * 32], ref[r * 32:(r + 1) * 32])
+        if first is None:
+            first = gpu
+            assert (gpu.sum(axis=2) > 0).mean() > 0.3
+        else:
+            assert np.array_equal(gpu, first), "frame %d differs from frame 0" % frame_no
+    del dev
 
 
 def test_synthetic_small_full_frame(pkg, O, ctx):
@@ -659,9 +698,11 @@ def test_feedback_order_renders_every_tile_once(pkg, ctx, monkeypatch):
             want, _ = gpu_render(pkg, plain, scene, w, h, depth)
             assert (want.sum(axis=2) > 0).any()
             for c in ctxs:
-                got = np.full((h, w, 3), -1., dtype=np.float64)         # a tile left out would keep its -1
-                gpu_render(pkg, c, scene, w, h, depth, out=got)
-                assert np.array_equal(got, want), "frame %d of the sequence differs with feedback on" % k
+                # into a caller-owned DEVICE buffer pre-filled with a sentinel: rm_render copies rows out of
+                # the context's own framebuffer, where a tile left out would still show the previous frame
+                got = device_render_with_sentinel(pkg, c, scene, w, h, depth)
+                assert np.array_equal(got[:h // 32 * 32], want[:h // 32 * 32]), "frame %d of the sequence differs with feedback on" % k
+                assert np.all(got[h // 32 * 32:] == -1.)
         # bands of a sharded frame (another launch geometry on the same stream, back and forth)
         for band in ((0, 11, 2), (1, 11, 2), (0, 11, 2)):
             want = np.zeros((352, 640, 3)); got = np.zeros((352, 640, 3))
@@ -939,6 +980,33 @@ def test_frame_wait_is_bounded(pkg):
     cx.close()
 
 
+def test_destroy_after_a_timeout_that_could_not_be_aborted_does_not_wait_for_the_device(pkg, monkeypatch):
+    """After RM_ERR_TIMEOUT the host reports and exits.  Where RCCL cannot abort the communicator
+    (ncclCommAbort absent or failing -- simulated by RM_TEST_NO_COMM_ABORT) the stuck collective
+    never ends, and rm_destroy must not call anything that waits for the device (hipFree does):
+    it releases nothing device-side and returns."""
+    import time
+
+    import torch
+    monkeypatch.setenv("RM_TEST_NO_COMM_ABORT", "1")
+    cx = pkg.backend.Context(0)
+    cx.upload(workloads.product_scene(pkg, "synthetic256").flatten())
+    w, h = 4096, 4096
+    p = pkg.backend.make_params(1.5, float(h), float(w), 10)
+    f = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    g = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    cx.comm_init(0, 1, pkg.backend.Context.comm_unique_id())          # a real communicator of one rank
+    for _ in range(3):
+        cx.frame_submit(p, f.data_ptr(), g.data_ptr(), None, slot=0)
+    with pytest.raises(pkg.BackendError) as e:
+        cx.frame_wait(0, timeout_ms=1)
+    assert e.value.status == pkg._lib.RM_ERR_TIMEOUT
+    t0 = time.perf_counter()
+    cx.close()
+    assert time.perf_counter() - t0 < 5.
+    torch.cuda.synchronize()                                           # (here the frames do complete: nothing is really stuck)
+
+
 def test_upload_of_the_resident_scene_is_not_repeated_and_a_changed_one_is(pkg, O):
     """rm_scene_upload compares the device image it builds with the resident one: the same
     scene again (any camera) costs no copy; any change of a primitive, material or light does,
@@ -957,6 +1025,20 @@ def test_upload_of_the_resident_scene_is_not_repeated_and_a_changed_one_is(pkg, 
     scene.lights[1] = pkg.create_light(pkg.Vec3f(20., 20., 20.), pkg.Vec3f(1., .5, .5), 0.5)
     c, _ = gpu_render(pkg, cx, scene, w, h, depth)
     assert cx.uploads() == (3, 2) and not np.array_equal(b, c)
+    # identity is decided on the bytes of the description, not on a digest of them: flipping the
+    # sign bit of an EVEN number of doubles (mirroring a sphere in x and y) is exactly what a
+    # multiplicative word hash cannot see in its top bit
+    mirrored = pkg.Scene()
+    mirrored.camera = pkg.Vec3f(0., 5., 0.)
+    plain = pkg.Scene()
+    plain.camera = pkg.Vec3f(0., 5., 0.)
+    for sc, sx in ((plain, 1.), (mirrored, -1.)):
+        sc.shapes.append(pkg.sphere.create(pkg.Vec3f(3. * sx, 2. * sx, -12.), 2., pkg.Reflectance.create_default()))
+        sc.lights.append(pkg.create_light(pkg.Vec3f(0., 0., 0.), pkg.Vec3f(1., 1., 1.), 1.))
+    e, _ = gpu_render(pkg, cx, plain, 320, 224, 3)
+    calls, copies = cx.uploads()
+    f, _ = gpu_render(pkg, cx, mirrored, 320, 224, 3)
+    assert cx.uploads() == (calls + 1, copies + 1) and not np.array_equal(e, f)
     # the overlapped host copy against a device-resident render of the same frame
     import torch
     dev = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")

@@ -135,4 +135,6 @@ def test_repr_c_structs_have_the_header_layout():
 def test_status_codes_used_by_the_shim_exist():
     text = open(RUST).read()
     assert "if status != 0" in text and "panic!" in text            # non-zero status -> panic, like the reference
-    assert "rm_host_alloc" in text and "rm_scene_upload" in text
+    assert "rm_render_rows" in text and "rm_scene_upload" in text
+    # the staging frame belongs to the library: the shim neither allocates nor frees page-locked memory per frame
+    assert "rm_host_free(self" not in text
