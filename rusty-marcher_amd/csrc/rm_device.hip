@@ -214,7 +214,6 @@ struct rm_ctx {
 static void hostio_destroy(rm_ctx *ctx, bool device_ok);
 struct rm_band;
 static bool hostio_packs(rm_ctx *ctx, size_t band_bytes);
-static rm_status hostio_frame_to_rows(rm_ctx *ctx, const rm_band &band, uint32_t frame_width, double *const *rows);
 
 static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
     if (ctx) ctx->error = msg;
@@ -1024,20 +1023,18 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     // into rows of rows; smaller ones are copied as they are.
     const size_t row_bytes = (size_t)params->frame_width * 3u * sizeof(double);
     const uint32_t n_rows = band.count();
+    if (host_rgb && n_rows > 0 && hostio_packs(ctx, (size_t)n_rows * 32u * row_bytes)) {
+        std::vector<double *> rows(params->frame_height);
+        for (uint32_t y = 0; y < params->frame_height; y++) rows[y] = host_rgb + (size_t)y * params->frame_width * 3u;
+        return rm_render_rows(ctx, params, rows.data(), timing);
+    }
     RM_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     st = launch_render(ctx, params, band, ctx->d_frame, nullptr, ctx->stream);
     if (st != RM_OK) return st;
     RM_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     double d2h_ms = 0.;
-    if (host_rgb && n_rows > 0 && hostio_packs(ctx, (size_t)n_rows * 32u * row_bytes)) {
-        const auto t0 = std::chrono::steady_clock::now();
-        std::vector<double *> rows(params->frame_height);
-        for (uint32_t y = 0; y < params->frame_height; y++) rows[y] = host_rgb + (size_t)y * params->frame_width * 3u;
-        st = hostio_frame_to_rows(ctx, band, params->frame_width, rows.data());
-        if (st != RM_OK) return st;
-        d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    } else if (host_rgb && n_rows > 0) {
+    if (host_rgb && n_rows > 0) {
         // Only the owned rows are copied: rows below the last whole patch row keep the
         // caller's previous contents, as in the reference (renderer.rs:53).
         RM_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -9,6 +9,7 @@
 //   rows_of_rows   rm_render_rows into the per-row allocations (the reference's layout)
 //   display_only   rm_render_display: f64 frame resident on the device, only fb.to_vec() comes
 //                  back (what main.rs:337-346 blits), into pageable and into page-locked memory
+//                  -- synchronous calls -- and as a render loop with frames in flight
 //   fetch_rows     rm_fetch_rows of the resident frame (save_to_file's read-back, on demand)
 //
 // and checks that all of them hold the same frame bit for bit.  Prints ONE JSON line.
@@ -49,6 +50,7 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--fast-fp")) fast = true;
         else { std::fprintf(stderr, "usage: rm_seam [--scene demo|OBJFILE] [--width W] [--height H] [--depth D] [--frames N] [--fast-fp]\n"); return 2; }
     }
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);     // frames in flight: a hardware queue per slot's stream (before HIP starts)
     try {
         scene::Scene sc = scene_arg == "demo" ? scene::Scene::create_default() : scene::Scene::open_obj(scene_arg);
         renderer::Renderer r = renderer::create_renderer(1.5, (double)height, (double)width);
@@ -125,6 +127,46 @@ int main(int argc, char **argv) {
         const bool pinned_equal = std::memcmp(pinned, want8.data(), rendered) == 0;
         rm_host_free(ctx, pinned);
 
+        // ---- display only, a render LOOP: frames in flight (rm_frame_submit_to_host, four slots, each on a
+        // stream of its own): frame k+1..k+3 render while the bytes of frame k cross the link; the camera
+        // moves between frames (rm_camera_update, the scene stays resident).  What a loop gets that need
+        // not have frame k in hand before it starts k+1 -- rm_walk is this loop with files behind it.
+        double pipelined_fps = 0.;
+        bool pipelined_equal = false;
+        {
+            const unsigned n_slots = RM_MAX_FRAME_SLOTS, n_loop = std::max(60u, frames * 6u);
+            const size_t rows32 = (height / 32) * 32, bytes8 = rows32 * width * 3;
+            void *d_rgb[RM_MAX_FRAME_SLOTS] = {}, *d_gather[RM_MAX_FRAME_SLOTS] = {}, *d_disp[RM_MAX_FRAME_SLOTS] = {}, *h_disp[RM_MAX_FRAME_SLOTS] = {};
+            for (unsigned k = 0; k < n_slots; k++) {
+                check(rm_buffer_alloc(ctx, width * height * 3 * sizeof(double), &d_rgb[k]), ctx);
+                check(rm_buffer_alloc(ctx, bytes8, &d_gather[k]), ctx);
+                check(rm_buffer_alloc(ctx, bytes8, &d_disp[k]), ctx);
+                check(rm_host_alloc(ctx, bytes8, &h_disp[k]), ctx);
+            }
+            const rm_vec3 cam0 = sc.camera.c();
+            auto t0 = clk::now();
+            for (unsigned f = 0; f < n_slots * 2 + n_loop; f++) {
+                if (f == n_slots * 2) {                                  // warmed up: drain, start the clock
+                    for (unsigned k = 0; k < n_slots; k++) check(rm_frame_wait(ctx, k), ctx);
+                    t0 = clk::now();
+                }
+                const unsigned k = f % n_slots;
+                check(rm_frame_wait(ctx, k), ctx);                         // the slot's previous frame is in h_disp[k]: consumed here
+                check(rm_camera_update(ctx, rm_vec3{cam0.x + 0.01 * (f % 7), cam0.y, cam0.z}), ctx);
+                check(rm_frame_submit_to_host(ctx, &p, d_rgb[k], d_gather[k], d_disp[k], h_disp[k], k), ctx);
+            }
+            for (unsigned k = 0; k < n_slots; k++) check(rm_frame_wait(ctx, k), ctx);
+            pipelined_fps = n_loop / std::chrono::duration<double>(clk::now() - t0).count();
+            // one more frame at the original camera: the same bytes as the synchronous call's
+            check(rm_camera_update(ctx, cam0), ctx);
+            check(rm_frame_submit_to_host(ctx, &p, d_rgb[0], d_gather[0], d_disp[0], h_disp[0], 0), ctx);
+            check(rm_frame_wait(ctx, 0), ctx);
+            pipelined_equal = std::memcmp(h_disp[0], want8.data(), bytes8) == 0;
+            for (unsigned k = 0; k < n_slots; k++) {
+                rm_buffer_free(ctx, d_rgb[k]); rm_buffer_free(ctx, d_gather[k]); rm_buffer_free(ctx, d_disp[k]); rm_host_free(ctx, h_disp[k]);
+            }
+        }
+
         // ---- the f64 rows of the resident frame, on demand
         framebuffer::FrameBuffer fb2 = framebuffer::create_frame_buffer(width, height);
         std::vector<double> t_fetch;
@@ -147,14 +189,17 @@ int main(int argc, char **argv) {
                      "\"flat\": {\"ms_per_call\": %.4f, \"mpx_per_s\": %.1f, \"what\": \"rm_render into one flat pageable array, median\"}, "
                      "\"display_only\": {\"ms_per_call\": %.4f, \"frames_per_s\": %.1f, \"kernel_ms\": %.4f, \"identical_to_to_vec_of_rows\": %s, "
                      "\"into_page_locked\": {\"ms_per_call\": %.4f, \"frames_per_s\": %.1f, \"identical\": %s}, "
+                     "\"render_loop_frames_in_flight\": {\"frames_per_s\": %.1f, \"frames_in_flight\": %u, \"identical\": %s, "
+                     "\"what\": \"rm_frame_submit_to_host, camera moving between frames, display bytes into page-locked memory\"}, "
                      "\"what\": \"rm_render_display: f64 frame stays on the device, fb.to_vec() into host memory, synchronous, median\"}, "
                      "\"fetch_rows\": {\"ms_per_call\": %.4f, \"identical\": %s}}\n",
                      scene_arg.c_str(), width, height, depth, frames, threads, m_rows, px / m_rows / 1e3, median(t_rows_kernel),
                      (unsigned long long)bytes, (unsigned long long)patches, (unsigned long long)sent, rows_equal_flat ? "true" : "false",
                      m_flat, px / m_flat / 1e3, m_disp, 1e3 / m_disp, median(t_disp_kernel), display_equal ? "true" : "false", m_pin,
-                     1e3 / m_pin, pinned_equal ? "true" : "false", median(t_fetch), fetch_equal ? "true" : "false");
+                     1e3 / m_pin, pinned_equal ? "true" : "false", pipelined_fps, (unsigned)RM_MAX_FRAME_SLOTS, pipelined_equal ? "true" : "false",
+                     median(t_fetch), fetch_equal ? "true" : "false");
         std::fclose(json);
-        return (rows_equal_flat && display_equal && pinned_equal && fetch_equal) ? 0 : 3;
+        return (rows_equal_flat && display_equal && pinned_equal && pipelined_equal && fetch_equal) ? 0 : 3;
     } catch (const Panic &p) {
         std::fprintf(stderr, "panic: %s (status %d)\n", p.what(), (int)p.status);
         return 101;

@@ -1025,6 +1025,14 @@ def test_upload_of_the_resident_scene_is_not_repeated_and_a_changed_one_is(pkg, 
     scene.lights[1] = pkg.create_light(pkg.Vec3f(20., 20., 20.), pkg.Vec3f(1., .5, .5), 0.5)
     c, _ = gpu_render(pkg, cx, scene, w, h, depth)
     assert cx.uploads() == (3, 2) and not np.array_equal(b, c)
+    # the frame that came through the host path against a device-resident render of the same frame
+    import torch
+    dev = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+    p.flags = _FLAGS["value"]
+    cx.render_device(p, dev.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), c)
     # identity is decided on the bytes of the description, not on a digest of them: flipping the
     # sign bit of an EVEN number of doubles (mirroring a sphere in x and y) is exactly what a
     # multiplicative word hash cannot see in its top bit
@@ -1039,14 +1047,6 @@ def test_upload_of_the_resident_scene_is_not_repeated_and_a_changed_one_is(pkg, 
     calls, copies = cx.uploads()
     f, _ = gpu_render(pkg, cx, mirrored, 320, 224, 3)
     assert cx.uploads() == (calls + 1, copies + 1) and not np.array_equal(e, f)
-    # the overlapped host copy against a device-resident render of the same frame
-    import torch
-    dev = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
-    p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
-    p.flags = _FLAGS["value"]
-    cx.render_device(p, dev.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(dev.cpu().numpy(), c)
     cx.close()
 
 
