@@ -303,6 +303,15 @@ rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rg
 rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
                               void *hip_stream);
 
+/* Tile classification (the launch in front of the render launch: one lane per 16x4 tile tests the cone of
+ * the tile's primary rays against every primitive's bounds -- the BoundingBox the reference computes and never
+ * consults, shapes.rs:34-86; tiles nothing can be hit in are filled with the primary-miss value there,
+ * renderer.rs:305, and never get a wave): the tiles of the last render launch of this context and how
+ * many of them the classification listed for rendering (all of them when it was off: RM_TILE_CLASSIFY=0,
+ * small frames, scenes of many primitives).  hip_stream: the stream that launch was enqueued on (NULL: whichever
+ * the context's last render launch went to).  Waits for the device. */
+rm_status rm_tile_stats(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t *tiles_listed);
+
 /* Device framebuffer of the last rm_render(.., NULL, ..) and its size in bytes. */
 rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes);
 

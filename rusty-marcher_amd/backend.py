@@ -72,6 +72,12 @@ class Context:
     def fetch_rows(self, rows, patch_row_begin=0, patch_row_end=0):
         _lib.check(self.L.rm_fetch_rows(self.ptr, self.row_pointers(rows), patch_row_begin, patch_row_end), self.ptr)
 
+    def tile_stats(self, stream=None):
+        """(tiles of the last render launch, tiles the classification listed for rendering)"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(self.L.rm_tile_stats(self.ptr, C.c_void_p(stream) if stream else None, C.byref(a), C.byref(b)), self.ptr)
+        return a.value, b.value
+
     def hostio_stats(self):
         """What the last host-bound call moved: bytes over the link, patches, patches sent, threads."""
         b, p, s, t = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)

@@ -138,6 +138,19 @@ struct rm_feedback {
 
 struct rm_hostio;   // rm_hostio.inc: staging buffer, row-scatter threads, display frame
 
+// The classification's output for the render launches on one stream: a mask per tile.  (Launches on a
+// stream are ordered: a render launch reads what the classification launch in front of it wrote, and the
+// next classification overwrites it only after that render launch is over.  Classifying a frame ahead on
+// a stream of its own was measured and dropped: the two cross-stream events cost more than the 3-8 us of
+// the classification they hid -- demo scene 1080p 99.8 against 81.2 us per frame.)
+struct rm_tile_lists {
+    hipStream_t stream = nullptr;
+    uint32_t cap = 0;                 // tiles the masks have room for
+    void *block = nullptr;            // mask[cap] u64
+    uint64_t used = 0;
+    unsigned long long *mask() const { return static_cast<unsigned long long *>(block); }
+};
+
 struct rm_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -179,6 +192,13 @@ struct rm_ctx {
     int feedback_target = -1;         // RM_FEEDBACK_TARGET: tiles the list should hold (-1: two per wave slot; 0: fixed threshold)
     std::vector<rm_feedback> feedback;
     uint64_t feedback_clock = 0, scene_epoch = 0;
+    // tile classification (rm_classify.hip): RM_TILE_CLASSIFY=0 never, 1 whenever the scene allows; unset:
+    // launches of RM_CLASSIFY_MIN_TILES tiles and more
+    int classify_mode = -1;
+    std::vector<rm_tile_lists> tile_lists;
+    uint32_t last_launch_tiles = 0;   // rm_tile_stats: the last render launch's tiles, and whether they were classified
+    bool last_launch_classified = false;
+    hipStream_t last_launch_stream = nullptr;
 
     // device framebuffer of rm_render
     double *d_frame = nullptr;
@@ -313,6 +333,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FEEDBACK_US")) ctx->feedback_us = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_FEEDBACK_TARGET")) ctx->feedback_target = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
+    if (const char *env = std::getenv("RM_TILE_CLASSIFY")) ctx->classify_mode = env[0] == '1' ? 1 : 0;
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
@@ -346,6 +367,8 @@ void rm_destroy(rm_ctx *ctx) {
         }
         for (rm_feedback &f : ctx->feedback)
             if (f.block) (void)hipFree(f.block);
+        for (rm_tile_lists &t : ctx->tile_lists)
+            if (t.block) (void)hipFree(t.block);
         if (ctx->d_scene) (void)hipFree(ctx->d_scene);
         if (ctx->d_frame) (void)hipFree(ctx->d_frame);
         if (ctx->d_backproject) (void)hipFree(ctx->d_backproject);
@@ -559,7 +582,15 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
         // ceiling of the Cornell box, any wall along z).  Radius -1: the cull drops it outright.
         bool same_x = true, same_y = true;
         for (uint32_t i = 1; i < nv; i++) { same_x = same_x && v[i].x == v[0].x; same_y = same_y && v[i].y == v[0].y; }
-        if (same_x || same_y) {
+        // Likewise two CONSECUTIVE vertices with the same x and the same y (a wall along z cut into triangles:
+        // the red wall of the Cornell box): the cross product of that edge is x y' - y x' with (x, y) == (x', y')
+        // bit for bit -- the same product twice, exactly zero, never > 0 -- for every hit point.
+        bool twin_edge = false;
+        for (uint32_t i = 0; i < nv; i++) {
+            const rm_vec3 &p = v[i], &q = v[(i + 1u) % nv];
+            twin_edge = twin_edge || (p.x == q.x && p.y == q.y);
+        }
+        if (same_x || same_y || twin_edge) {
             double *w = &blob[H.off_bounds + 4u * pid];
             w[0] = w[1] = w[2] = 0.; w[3] = -1.;
             return;
@@ -806,6 +837,39 @@ static rm_status feedback_for(rm_ctx *ctx, hipStream_t stream, const uint64_t ke
     return RM_OK;
 }
 
+static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 2048, RM_CLASSIFY_STREAMS = 8;
+// What a lane of the classification spends on its share of a patch's primitives, in vector instructions: ~22
+// per bounding sphere, ~110 more for the edge and plane tests of a planar primitive.  Beyond this the launch
+// is not worth its time.
+static constexpr uint32_t RM_CLASSIFY_MAX_COST = 4000;
+
+static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tiles, rm_tile_lists **out) {
+    rm_tile_lists *t = nullptr;
+    for (rm_tile_lists &g : ctx->tile_lists)
+        if (g.stream == stream) t = &g;
+    if (!t) {
+        if (ctx->tile_lists.size() >= RM_CLASSIFY_STREAMS) {       // forget the stream used longest ago
+            size_t old = 0;
+            for (size_t i = 1; i < ctx->tile_lists.size(); i++)
+                if (ctx->tile_lists[i].used < ctx->tile_lists[old].used) old = i;
+            if (ctx->tile_lists[old].block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].block));   // (waits for the device)
+            ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)old);
+        }
+        ctx->tile_lists.emplace_back();
+        t = &ctx->tile_lists.back();
+        t->stream = stream;
+    }
+    t->used = ++ctx->feedback_clock;
+    if (!t->block || t->cap < n_tiles) {
+        if (t->block) RM_HIP(ctx, hipFree(t->block));             // (waits for the device: nothing reads the old masks any more)
+        t->block = nullptr;
+        t->cap = n_tiles;
+        RM_HIP(ctx, hipMalloc(&t->block, (size_t)n_tiles * sizeof(unsigned long long)));
+    }
+    *out = t;
+    return RM_OK;
+}
+
 // Which kernel instantiation a render with these params launches, and how.
 struct rm_kernel_choice {
     const void *fn = nullptr;
@@ -952,6 +1016,32 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     RM_HIP(ctx, hipMemsetAsync(d_stamps, 0, n_waves * 32, stream));
     a.debug_stamps = d_stamps;
 #endif
+    // Tile classification in front of the render launch (rm_classify.hip): tiles whose primary rays can hit
+    // nothing are filled there and never get a wave; the others are listed, with the primitives their primary
+    // rays can reach.  Worth a launch of its own from a few thousand tiles on, in scenes whose primitives a
+    // lane can get through.  Only the primary rays are concerned: frames are bit-identical with it off.
+    {
+        const uint32_t n_planar = ctx->H.n_polygons + ctx->H.n_triangles;
+        const uint32_t cost = (22u * n_prims_all + 110u * n_planar) / 16u;   // a lane's share of the patch step
+        const bool classify = ctx->classify_mode != 0 && !ctx->debug_empty && per_wg == 1u && n_prims_all > 0u &&
+                              cost <= RM_CLASSIFY_MAX_COST && (ctx->classify_mode == 1 || a.n_tiles >= RM_CLASSIFY_MIN_TILES);
+        ctx->last_launch_tiles = a.n_tiles;
+        ctx->last_launch_classified = classify;
+        ctx->last_launch_stream = stream;
+        if (classify) {
+            rm_tile_lists *tl = nullptr;
+            rm_status cst = tile_lists_for(ctx, stream, a.n_tiles, &tl);
+            if (cst != RM_OK) return cst;
+            ClassifyArgs o{};
+            o.tile_mask = tl->mask();
+            o.n_prims = n_prims_all;
+            // sixteen lanes to a 32x32 patch, four patches to a wave
+            void *cargs[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&o};
+            RM_HIP(ctx, hipLaunchKernel(rm_classify_kernel(n_planar > 0u), dim3((a.n_tiles / 16u + 3u) / 4u), dim3(64), cargs, 0, stream));
+            a.tile_mask = o.tile_mask;
+            a.mask_exact = n_prims_all <= 64u ? 1u : 0u;
+        }
+    }
     void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
     if (fb) fb->cur = (fb->cur + 1) % 3;
@@ -1073,6 +1163,37 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
                   k.cull ? "true" : "false", k.edges ? "true" : "false", k.feedback ? "true" : "false");
+    return RM_OK;
+}
+
+rm_status rm_tile_stats(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t *tiles_listed) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_tile_stats: NULL ctx");
+    RM_HIP(ctx, hipSetDevice(ctx->device));
+    RM_HIP(ctx, hipDeviceSynchronize());
+    const uint32_t n = ctx->last_launch_tiles;
+    uint32_t listed = n;
+    for (const rm_tile_lists &t : ctx->tile_lists)
+        if (t.stream == (hip_stream ? (hipStream_t)hip_stream : ctx->last_launch_stream) && t.block && ctx->last_launch_classified && n <= t.cap) {
+            std::vector<unsigned long long> m(n);
+            RM_HIP(ctx, hipMemcpy(m.data(), t.mask(), (size_t)n * 8u, hipMemcpyDeviceToHost));
+            listed = 0;
+            uint32_t hist[64] = {};
+            uint64_t bits = 0;
+            for (unsigned long long v : m) {
+                listed += v != 0ull;
+                for (int b = 0; b < 64 && v != ~0ull; b++)
+                    if (v >> b & 1ull) { hist[b]++; bits++; }
+            }
+            if (std::getenv("RM_DEBUG_CLASSIFY")) {
+                std::fprintf(stderr, "[rm_classify] %u of %u tiles have something to hit, %.2f primitives each; tiles per pid:", listed, n,
+                             listed ? (double)bits / listed : 0.);
+                for (int b = 0; b < 64; b++)
+                    if (hist[b]) std::fprintf(stderr, " %d:%u", b, hist[b]);
+                std::fprintf(stderr, "\n");
+            }
+        }
+    if (tiles) *tiles = n;
+    if (tiles_listed) *tiles_listed = listed;
     return RM_OK;
 }
 

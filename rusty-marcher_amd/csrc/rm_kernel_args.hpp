@@ -64,7 +64,25 @@ struct KernelArgs {
     uint32_t fb_cap;                         // workgroups [0, fb_cap) take the list, the rest the tiles in order
     uint32_t fb_long_ticks;                  // the threshold while there is no histogram (100 MHz ticks)
     uint32_t fb_target;                      // tiles the list should hold (0: fb_long_ticks is the threshold)
+    // Tile classification (rm_classify.hip): a launch of one lane per tile has tested the cone of each tile's
+    // primary rays against the primitives' bounds.  tile_mask[tile] == 0: no primary ray of the tile can hit
+    // anything -- its wave stores the primary-miss value (zeros, renderer.rs:305) and leaves; else, in scenes
+    // of up to 64 primitives (mask_exact), the primitives (bit = pid) the tile's primary rays can reach.
+    // NULL: off.
+    const unsigned long long *tile_mask;
+    uint32_t mask_exact;
+    uint32_t _pad_mask;
 };
+
+// What the classification launch gets besides the render launch's own arguments.
+struct ClassifyArgs {
+    unsigned long long *tile_mask;
+    uint32_t n_prims;
+    uint32_t _pad;
+};
+
+// rm_classify.hip
+const void *rm_classify_kernel(bool edges);
 
 // Feedback histogram: tile times in 100 MHz ticks, four buckets per octave (bucket b holds
 // [edge(b), edge(b+1)), edge(b) = (4 + b % 4) << (b / 4) >> 2: 1, 1, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7, 8, 10, ...);

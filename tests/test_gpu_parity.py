@@ -663,6 +663,83 @@ def test_bundle_cull_equals_plain_walk_bitwise(pkg, ctx, monkeypatch):
         plain_ctx.close()
 
 
+def test_tile_classification_is_bitwise_invisible(pkg, O, monkeypatch):
+    """The classification launch in front of the render launch (rm_classify.hip: one lane per tile tests the
+    cone of the tile's primary rays against every primitive's bounds; tiles nothing can be hit in are
+    filled there and get no wave, the others are listed with the primitives their primary rays can reach)
+    only decides WHICH tiles get a wave and which primitives their primary rays test: every frame must
+    equal the frame of a context without it bit for bit -- f64 and display bytes, into buffers pre-filled
+    with a sentinel -- for the demo scene, the Cornell box (from outside and from inside it), 256 spheres
+    (list only: more primitives than a mask holds), cameras inside and behind things, bands and strided
+    packed bands, tiny frames whose tiles are wider than the cone test allows, and a scene seen from a
+    camera at a NaN (everything kept)."""
+    import torch
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    cls = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_TILE_CLASSIFY")
+    demo = pkg.Scene.create_default()
+    cornell = workloads.product_scene(pkg, "cornell")
+    synth = workloads.product_scene(pkg, "synthetic256")
+    mixed = pkg.Scene()
+    refl = pkg.Reflectance.create_default()
+    glass = pkg.Reflectance.create_default()
+    glass.is_glass_like, glass.refractive_index, glass.reflection = True, 1.5, 0.3
+    for k in range(9):
+        mixed.shapes.append(pkg.sphere.create(pkg.Vec3f(-8. + 2. * k, -1. + 0.5 * (k % 3), -14. - k), 0.9, glass if k % 3 == 0 else refl))
+    mixed.shapes.append(pkg.polygon.ConvexPolygon.create([pkg.Vec3f(-9., -3., -4.), pkg.Vec3f(9., -3., -4.), pkg.Vec3f(9., -2., -30.), pkg.Vec3f(-9., -2., -30.)][::-1], refl))
+    mixed.shapes.append(pkg.polygon.ConvexPolygon.create([pkg.Vec3f(0., 4., -20.), pkg.Vec3f(-2., 2., -21.), pkg.Vec3f(0., 0., -20.), pkg.Vec3f(2., 1., -19.), pkg.Vec3f(2., 3., -19.)], refl))
+    mixed.lights.append(pkg.create_light(pkg.Vec3f(0., 10., 0.), pkg.Vec3f(1., 1., 1.), 1.))
+    cases = [(demo, (0., 0., 0.), 1920, 1080, 5, None), (demo, (0., 5., 0.), 640, 352, 5, None), (demo, (-5., 0., -16.), 640, 352, 6, None),
+             (demo, (0., 0., -60.), 640, 352, 4, None), (demo, (0., 0., 0.), 64, 64, 3, None), (demo, (0., 0., 0.), 1920, 1080, 5, (3, 30, 4)),
+             (cornell, (0., 0., 0.), 1920, 1080, 5, None), (cornell, (0., 1., -498.), 800, 608, 3, None), (cornell, (3., 0.5, -300.), 640, 352, 3, (1, 9)),
+             (synth, (0., 0., 0.), 1024, 768, 6, None), (synth, (2., 1., -30.), 640, 352, 8, None),
+             (mixed, (0., 0., 0.), 800, 608, 5, None), (mixed, (0., 2., -12.), 640, 352, 5, None), (demo, (float("nan"), 0., 0.), 320, 224, 3, None)]
+    try:
+        for k, (scene, cam, w, h, depth, band) in enumerate(cases):
+            scene.camera = pkg.Vec3f(*cam)
+            p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
+            p.flags = _FLAGS["value"]
+            outs = []
+            for c in (plain, cls):
+                c.upload(scene.flatten())
+                f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+                u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+                c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())      # (a second frame: the counters take turns)
+                torch.cuda.synchronize()
+                outs.append((f64.cpu().numpy(), u8.cpu().numpy()))
+            assert outs[0][0].tobytes() == outs[1][0].tobytes(), "case %d: f64 frame differs with the classification on" % k
+            assert np.array_equal(outs[0][1], outs[1][1]), "case %d: display bytes differ" % k
+            if band is None and cam[0] == cam[0]:
+                n = h // 32 * 32
+                assert not (outs[1][0][:n] == -1.).any()
+        # against the oracle once, through the classified path
+        demo.camera = pkg.Vec3f(0., 0., 0.)
+        got, _ = gpu_render(pkg, cls, demo, 640, 352, 5)
+        compare(got, O.render(O.OracleScene.create_default(), 640, 352, max_depth=5))
+        # packed display bytes of a strided band (a rank's chunk of the gather buffer)
+        w, h = 640, 352
+        p = pkg.backend.make_params(workloads.FOV, float(h), float(w), 5, (1, 11, 3))
+        p.flags = _FLAGS["value"] | 4                               # RM_FLAG_U8_COMPACT
+        packs = []
+        for c in (plain, cls):
+            c.upload(demo.flatten())
+            f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+            u8 = torch.full((4 * 32, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+            torch.cuda.synchronize()
+            packs.append((f64.cpu().numpy(), u8.cpu().numpy()))
+        assert packs[0][0].tobytes() == packs[1][0].tobytes() and np.array_equal(packs[0][1], packs[1][1])
+        assert not (packs[1][1] == 201).all(axis=2).any()
+    finally:
+        plain.close()
+        cls.close()
+
+
 def test_feedback_order_renders_every_tile_once(pkg, ctx, monkeypatch):
     """Frame-to-frame feedback (rm_device.hip, rm_feedback): the tiles that took long in the
     previous frame on a stream are dispatched first in the next.  Only the ORDER of dispatch may
