@@ -837,7 +837,7 @@ static rm_status feedback_for(rm_ctx *ctx, hipStream_t stream, const uint64_t ke
     return RM_OK;
 }
 
-static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 2048, RM_CLASSIFY_STREAMS = 8;
+static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 8192, RM_CLASSIFY_STREAMS = 8;
 // What a lane of the classification spends on its share of a patch's primitives, in vector instructions: ~22
 // per bounding sphere, ~110 more for the edge and plane tests of a planar primitive.  Beyond this the launch
 // is not worth its time.
