@@ -50,6 +50,10 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PIXEL = 24            # 3 x f64 written per pixel (framebuffer.rs Vec3f), SURVEY.md 8d
 FEEDBACK_NOTE = ("frame-to-frame feedback: the tiles that took longest in the previous frame on the stream are dispatched "
                  "first (RM_FEEDBACK=0 switches it off); every tile of every frame is rendered in full")
+CLASSIFY_NOTE = ("a launch of 16 lanes per 32x32 patch in front of the render launch tests the cone of every tile's primary rays "
+                 "against the primitives' bounds (RM_TILE_CLASSIFY=0 switches it off): tiles nothing can be hit in get a wave "
+                 "that stores the primary-miss value and leaves; every other pixel is traced in full; kernel_ms and ms_per_step "
+                 "include that launch")
 WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
 WARMUP_PROBE = 8                # launches timed to find out how many that is
 
@@ -228,6 +232,31 @@ def csrc_hash():
             h.update(name.encode())
             h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
+
+
+def pmc_for(cfg_id, kernel_name, kernel_ms):
+    """rocprofv3 PMC figures of a config's render launch (profiles/pmc_<cfg>.json, written by
+    profiles/summarise_round.py from passes of their own), quoted only while they belong to the build
+    that runs: same hash of the kernel sources, same kernel name.  -> (traffic, fp64_valu, note)"""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % cfg_id)
+    if not os.path.exists(path):
+        return None, None, "no profiles/pmc_%s.json" % cfg_id
+    try:
+        pmc = json.load(open(path))
+        if pmc.get("csrc_sha16") != csrc_hash() or pmc.get("kernel") != kernel_name:
+            return None, None, ("profiles/pmc_%s.json was collected on another build of the kernel sources "
+                                "(csrc hash / kernel name differ): traffic not reported" % cfg_id)
+        valu = {k: pmc.get(k) for k in ("valu_busy_frac", "valu_lanes_active_frac", "valu_wave_instructions",
+                                        "salu_wave_instructions", "wait_any_frac", "wait_inst_any_frac")}
+        if valu["valu_wave_instructions"] and kernel_ms:
+            # the bound that does apply: one 64-lane FP64 VALU instruction per SIMD per 4 cycles
+            # (1024 SIMDs, 2.4 GHz peak clock) against this run's kernel time
+            valu["valu_issue_frac_of_peak"] = valu["valu_wave_instructions"] * 4.0 / (1024 * 2.4e9 * kernel_ms * 1e-3)
+        return pmc.get("hbm_bytes_per_launch"), valu, (
+            "traffic and fp64_valu are rocprofv3 PMC figures of this command on this build (profiles/pmc_%s.json: "
+            "csrc hash and kernel name match), not measured in this run" % cfg_id)
+    except Exception as e:                              # noqa: BLE001
+        return None, None, "profiles/pmc_%s.json unreadable: %s" % (cfg_id, e)
 
 
 def cpu_baseline(O, workloads, cfg, budget_s=25.0):
@@ -623,6 +652,11 @@ def rank_main(args):
                 state["direct_note"] = "library communicator could not be created on every rank"
 
         best = paths[chosen]
+        tiles = None
+        if not use_dist:
+            n_t, n_lit = ctx.tile_stats(stream.cuda_stream)
+            tiles = {"tiles": n_t, "with_something_to_hit": n_lit,
+                     "classified": bool(n_lit != n_t)}
         frame, frame8 = frames[0], (frames8[0] if frames8 else None)
         image = images[0] if images else None
         px_launch = n_owned * 32 * w                                        # pixels one launch writes
@@ -726,41 +760,19 @@ def rank_main(args):
             if u8 is not None:
                 checks["display_bytes_differing_from_oracle"] = int((u8.cpu().numpy().reshape(-1) != O.to_vec(ref.copy())).sum())
         res = dict(cfg=cfg, paths=paths, chosen=chosen, kernel_name=kernel_name, n_owned=n_owned, c_rows=c_rows, cyclic=cyclic,
-                   host=host, piped=piped, checks=checks, px_launch=px_launch, best=best)
+                   host=host, piped=piped, checks=checks, px_launch=px_launch, best=best, tiles=tiles)
         ctx.close()
         torch.cuda.empty_cache()
         return res
 
-    def result(cfg, paths, chosen, note, kernel_name, n_owned, c_rows, cyclic, host, piped, checks, other):
+    def result(cfg, paths, chosen, note, kernel_name, n_owned, c_rows, cyclic, host, piped, checks, other, tiles=None):
         """The JSON line."""
         w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
         best = paths[chosen]
         px_launch = n_owned * 32 * w
         kernel_ms = best["kernel_ms"]
         achieved = px_launch * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
-        traffic, valu, pmc_note = None, None, "no profiles/pmc_latest.json for this config"
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path) and world == 1:
-            try:
-                pmc = json.load(open(pmc_path))
-                if pmc.get("config") != args.config:
-                    pmc_note = "profiles/pmc_latest.json is of config %s" % pmc.get("config")
-                elif pmc.get("csrc_sha16") != csrc_hash() or pmc.get("kernel") != kernel_name:
-                    pmc_note = ("profiles/pmc_latest.json was collected on another build of the kernel sources "
-                                "(csrc hash / kernel name differ): traffic not reported")
-                else:
-                    traffic = pmc.get("hbm_bytes_per_launch")
-                    valu = {k: pmc.get(k) for k in ("valu_busy_frac", "valu_lanes_active_frac", "valu_wave_instructions",
-                                                    "salu_wave_instructions", "wait_any_frac", "wait_inst_any_frac")}
-                    if valu["valu_wave_instructions"]:
-                        # the bound that does apply: one 64-lane FP64 VALU instruction per SIMD per 4 cycles
-                        # (1024 SIMDs, 2.4 GHz peak clock) against this run's kernel time
-                        valu["valu_issue_frac_of_peak"] = (valu["valu_wave_instructions"] * 4.0
-                                                           / (1024 * 2.4e9 * kernel_ms * 1e-3))
-                    pmc_note = ("traffic and fp64_valu are rocprofv3 PMC figures of this command on this build "
-                                "(profiles/pmc_latest.json: csrc hash and kernel name match), not measured in this run")
-            except Exception as e:                      # noqa: BLE001
-                pmc_note = "profiles/pmc_latest.json unreadable: %s" % e
+        traffic, valu, pmc_note = pmc_for(args.config, kernel_name, kernel_ms) if world == 1 else (None, None, "PMC figures are per single-GPU launch")
         coll = {"none": "none (one GPU)",
                 "direct": "rm_frame_submit%s: %s from the C library" % ("_f64" if args.payload == "f64" else "",
                                                                        "ncclAllGather" if args.exchange == "allgather" else "grouped ncclSend / ncclRecv to rank 0"),
@@ -798,10 +810,13 @@ def rank_main(args):
                          "bytes_per_launch": px_launch * BYTES_PER_PIXEL,
                          "fp64_valu": valu,
                          "note": "path is FP64-VALU bound by construction (SURVEY.md 8d); achieved = 24 B x pixels "
-                                 "written / kernel time (HIP events on the launch stream); " + pmc_note},
+                                 "written / kernel time (HIP events on the launch stream around the K steps: a step is the "
+                                 "render launch and, where tiles are classified, the classification launch in front of it); " + pmc_note},
         }
         if kernel_name.rstrip(">").endswith("true"):                 # last template argument: FEEDBACK
             out["config"]["dispatch"] = FEEDBACK_NOTE
+        if tiles:
+            out["config"]["tiles"] = dict(tiles, note=CLASSIFY_NOTE)
         if world > 1 or args.force_dist:
             out["exchange_paths"] = paths
         if checks:
@@ -833,13 +848,16 @@ def rank_main(args):
                           "kernel": o["kernel_name"], "kernel_ms": o["best"]["kernel_ms"] if world == 1 else None,
                           "collective": o["chosen"],
                           "roofline_frac": (ach / HBM_PEAK_GBPS) if world == 1 else None})
+            if world == 1:
+                t_, v_, n_ = pmc_for(cid, o["kernel_name"], o["best"]["kernel_ms"])
+                other[-1].update(traffic=t_, fp64_valu=v_, pmc=n_, tiles=o["tiles"])
             if o["kernel_name"].rstrip(">").endswith("true"):         # last template argument: FEEDBACK
                 other[-1]["dispatch"] = FEEDBACK_NOTE
             o.clear()
 
     if rank == 0:
         out = result(r["cfg"], r["paths"], r["chosen"], None, r["kernel_name"], r["n_owned"], r["c_rows"], r["cyclic"],
-                     r["host"], r["piped"], r["checks"], other)
+                     r["host"], r["piped"], r["checks"], other, r["tiles"])
         if world == 1 and not args.no_cpu_baseline:
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, r["cfg"])

@@ -1,7 +1,9 @@
 #!/bin/bash
-# Collects rocprofv3 PMC counters for bench.py's render kernel, one --pmc pass per
-# counter group (separate runs, kernel-trace only -- never combined with sys traces).
+# Collects rocprofv3 PMC counters for bench.py's launches, one --pmc pass per counter group
+# (separate runs, kernel-trace only -- never combined with sys traces).
 # usage (on the GPU box, from the repo root):  bash profiles/run_pmc.sh <tag> [bench args]
+# -> gpurun_out/pmc_<tag>/summary.csv: mean counter value per launch, for the render kernel
+#    (rm_render_static) and for the classification kernel in front of it (rm_classify_tiles_kernel)
 set -u
 TAG=${1:-run}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -25,13 +27,15 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "rm_render_" not in row["Kernel_Name"]:
+        name = row["Kernel_Name"]
+        which = "render" if "rm_render_" in name else "classify" if "rm_classify_" in name else None
+        if which is None:
             continue
-        a = agg[row["Counter_Name"]]
+        a = agg[(which, row["Counter_Name"])]
         a[0] += float(row["Counter_Value"]); a[1] += 1
 with open(out + "/summary.csv", "w") as g:
-    g.write("counter,mean_per_launch,launches\n")
+    g.write("kernel,counter,mean_per_launch,launches\n")
     for k in sorted(agg):
-        g.write("%s,%.1f,%d\n" % (k, agg[k][0] / agg[k][1], agg[k][1]))
+        g.write("%s,%s,%.1f,%d\n" % (k[0], k[1], agg[k][0] / agg[k][1], agg[k][1]))
 print(open(out + "/summary.csv").read())
 PY
