@@ -71,7 +71,13 @@ struct KernelArgs {
     // NULL: off.
     const unsigned long long *tile_mask;
     uint32_t mask_exact;
-    uint32_t _pad_mask;
+    // The classification at the head of THIS launch (scenes of up to 56 primitives): its first cls_blocks
+    // workgroups classify -- four patches each, in the order the tiles are dispatched -- and write
+    // (mask_tag << 56) | mask; a render wave takes its tile's word once it carries this launch's tag.
+    // mask_tag == 0: the masks come from a launch of their own, ahead of this one.
+    uint32_t mask_tag;
+    uint32_t cls_blocks;
+    uint32_t cls_prims;
 };
 
 // What the classification launch gets besides the render launch's own arguments.

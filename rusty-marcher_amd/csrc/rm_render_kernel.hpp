@@ -80,6 +80,7 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, 
 #define RM_FAST 0
 #pragma clang fp contract(off)
 #include "rm_trace.inc"
+#include "rm_classify.inc"
 #include "rm_render_kernel.inc"
 #undef RM_FLAVOR_NS
 #undef RM_FAST
@@ -90,6 +91,7 @@ __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, 
 #define RM_FAST 1
 #pragma clang fp contract(fast)
 #include "rm_trace.inc"
+#include "rm_classify.inc"
 #include "rm_render_kernel.inc"
 #undef RM_FLAVOR_NS
 #undef RM_FAST
