@@ -186,6 +186,7 @@ struct rm_ctx {
     // (never), RM_CULL_COS overrides (A/B knobs).
     double cull_cos = 0.975;          // (synthetic-256: 0.9 1,911 us, 0.95 1,825, 0.97-0.98 1,777, 0.99 1,791, 0.999 1,847; cornell flat)
     uint32_t cull_min_prims = RM_CULL_MIN_PRIMS;   // RM_CULL_MIN (A/B knob)
+    bool cull_edges = true;           // RM_CULL_EDGES=0: the bundle cull without its edge test (A/B knob)
     bool force_unstaged = false;      // RM_FORCE_UNSTAGED=1 (A/B knob)
     int force_stack = 0;              // RM_FORCE_STACK=4|8|16|32: a deeper ray stack than the depth cap needs (A/B knob)
     bool debug_empty = false;         // RM_DEBUG_EMPTY=1: measure the dispatch floor of a launch geometry
@@ -347,6 +348,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_CULL_COS"))   // (the cone tests hold for half-angles below 90 degrees)
         ctx->cull_cos = std::max(0.05, std::atof(env));
     if (const char *env = std::getenv("RM_CULL_MIN")) ctx->cull_min_prims = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char *env = std::getenv("RM_CULL_EDGES")) ctx->cull_edges = env[0] != '0';
     *out = ctx;
     return RM_OK;
 }
@@ -909,7 +911,7 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     k->pow_mode = (ctx->integer_exponents && !ctx->force_generic_pow) ? POW_INTEGER : POW_GENERIC;
     k->fast = (p->flags & RM_FLAG_FAST_FP) != 0 || ctx->force_fast_fp;
     // the cull's edge test for planar primitives where there are several of them
-    k->edges = k->cull && ctx->H.n_polygons + ctx->H.n_triangles >= RM_CULL_EDGES_MIN_PLANAR;
+    k->edges = k->cull && ctx->cull_edges && ctx->H.n_polygons + ctx->H.n_triangles >= RM_CULL_EDGES_MIN_PLANAR;
     const int st = k->stack, pw = k->pow_mode;
     const bool f = k->fast;
     // Feedback where tile costs have a long tail: deep ray trees in scenes with a hierarchy (a
