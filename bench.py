@@ -54,6 +54,8 @@ CLASSIFY_NOTE = ("a launch of 16 lanes per 32x32 patch in front of the render la
                  "against the primitives' bounds (RM_TILE_CLASSIFY=0 switches it off): tiles nothing can be hit in get a wave "
                  "that stores the primary-miss value and leaves; every other pixel is traced in full; kernel_ms and ms_per_step "
                  "include that launch")
+ORDER_NOTE = ("patch order: the 32x32 patches that took longest in the previous frames on the stream are dispatched first "
+              "(RM_PATCH_ORDER=0 switches it off); every tile of every frame is rendered in full")
 WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
 WARMUP_PROBE = 8                # launches timed to find out how many that is
 
@@ -815,6 +817,8 @@ def rank_main(args):
         }
         if kernel_name.rstrip(">").endswith("true"):                 # last template argument: FEEDBACK
             out["config"]["dispatch"] = FEEDBACK_NOTE
+        elif kernel_name.rstrip(">").endswith("true, false"):        # the one before it: ORDER
+            out["config"]["dispatch"] = ORDER_NOTE
         if tiles:
             out["config"]["tiles"] = dict(tiles, note=CLASSIFY_NOTE)
         if world > 1 or args.force_dist:
@@ -853,6 +857,8 @@ def rank_main(args):
                 other[-1].update(traffic=t_, fp64_valu=v_, pmc=n_, tiles=o["tiles"])
             if o["kernel_name"].rstrip(">").endswith("true"):         # last template argument: FEEDBACK
                 other[-1]["dispatch"] = FEEDBACK_NOTE
+            elif o["kernel_name"].rstrip(">").endswith("true, false"):   # the one before it: ORDER
+                other[-1]["dispatch"] = ORDER_NOTE
             o.clear()
 
     if rank == 0:

@@ -148,6 +148,12 @@ struct rm_tile_lists {
     uint32_t cap = 0;                 // tiles the masks have room for
     void *block = nullptr;            // mask[cap] u64
     uint64_t used = 0;
+    // patch order (launches of up to 4,096 patches): cost[2][cap16] | order[2][cap16] u32, frames since the last reset
+    void *order_block = nullptr;
+    uint32_t order_cap = 0, order_frames = 0;
+    uint64_t order_key[3] = {0, 0, 0};
+    uint32_t *cost(uint32_t j) const { return static_cast<uint32_t *>(order_block) + (size_t)j * order_cap; }
+    uint32_t *order(uint32_t j) const { return static_cast<uint32_t *>(order_block) + (size_t)(2u + j) * order_cap; }
     // classification at the head of the render launch: the words carry the launch's tag (1..255)
     uint32_t tag = 0, tagged_tiles = 0;
     uint64_t tagged_scene = 0;
@@ -201,6 +207,7 @@ struct rm_ctx {
     // launches of RM_CLASSIFY_MIN_TILES tiles and more
     int classify_mode = -1;
     bool classify_in_launch = true;      // RM_CLASSIFY_IN_LAUNCH=0: always a launch of its own in front (A/B knob)
+    int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
     std::vector<rm_tile_lists> tile_lists;
     uint32_t last_launch_tiles = 0;   // rm_tile_stats: the last render launch's tiles, and whether they were classified
     bool last_launch_classified = false;
@@ -272,21 +279,21 @@ static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 // bundles; CULL: bundle culling, EDGES: its edge test for planar primitives, rm_trace.inc;
 // FEEDBACK: longest tiles of the previous frame first).
 #define RM_DECLARE_GROUP(g) \
-    const void *rm_pick_kernel_strict_g##g(bool edges, int stack, int pow_mode); \
-    const void *rm_pick_kernel_fast_g##g(bool edges, int stack, int pow_mode);
+    const void *rm_pick_kernel_strict_g##g(bool edges, bool order, int stack, int pow_mode); \
+    const void *rm_pick_kernel_fast_g##g(bool edges, bool order, int stack, int pow_mode);
 RM_DECLARE_GROUP(0) RM_DECLARE_GROUP(1) RM_DECLARE_GROUP(2) RM_DECLARE_GROUP(3) RM_DECLARE_GROUP(4)
 #undef RM_DECLARE_GROUP
 
-const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool feedback, int stack, int pow_mode) {
+const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool order, bool feedback, int stack, int pow_mode) {
     const int group = staged ? (cull ? 1 : 0) : !bvh ? 2 : feedback ? 4 : 3;
     if (staged && (bvh || feedback)) return nullptr;         // no such kernel: small scenes have no hierarchy
     if (!staged && !cull) return nullptr;                    // scenes in global memory always cull
     switch (group) {
-    case 0: return fast ? rm_pick_kernel_fast_g0(edges, stack, pow_mode) : rm_pick_kernel_strict_g0(edges, stack, pow_mode);
-    case 1: return fast ? rm_pick_kernel_fast_g1(edges, stack, pow_mode) : rm_pick_kernel_strict_g1(edges, stack, pow_mode);
-    case 2: return fast ? rm_pick_kernel_fast_g2(edges, stack, pow_mode) : rm_pick_kernel_strict_g2(edges, stack, pow_mode);
-    case 3: return fast ? rm_pick_kernel_fast_g3(edges, stack, pow_mode) : rm_pick_kernel_strict_g3(edges, stack, pow_mode);
-    default: return fast ? rm_pick_kernel_fast_g4(edges, stack, pow_mode) : rm_pick_kernel_strict_g4(edges, stack, pow_mode);
+    case 0: return fast ? rm_pick_kernel_fast_g0(edges, order, stack, pow_mode) : rm_pick_kernel_strict_g0(edges, order, stack, pow_mode);
+    case 1: return fast ? rm_pick_kernel_fast_g1(edges, order, stack, pow_mode) : rm_pick_kernel_strict_g1(edges, order, stack, pow_mode);
+    case 2: return fast ? rm_pick_kernel_fast_g2(edges, order, stack, pow_mode) : rm_pick_kernel_strict_g2(edges, order, stack, pow_mode);
+    case 3: return fast ? rm_pick_kernel_fast_g3(edges, order, stack, pow_mode) : rm_pick_kernel_strict_g3(edges, order, stack, pow_mode);
+    default: return fast ? rm_pick_kernel_fast_g4(edges, order, stack, pow_mode) : rm_pick_kernel_strict_g4(edges, order, stack, pow_mode);
     }
 }
 
@@ -341,6 +348,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_DEBUG_EMPTY")) ctx->debug_empty = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_CLASSIFY")) ctx->classify_mode = env[0] == '1' ? 1 : 0;
     if (const char *env = std::getenv("RM_CLASSIFY_IN_LAUNCH")) ctx->classify_in_launch = env[0] == '1';
+    if (const char *env = std::getenv("RM_PATCH_ORDER")) ctx->patch_order_mode = env[0] == '1' ? 1 : 0;
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
@@ -375,8 +383,10 @@ void rm_destroy(rm_ctx *ctx) {
         }
         for (rm_feedback &f : ctx->feedback)
             if (f.block) (void)hipFree(f.block);
-        for (rm_tile_lists &t : ctx->tile_lists)
+        for (rm_tile_lists &t : ctx->tile_lists) {
             if (t.block) (void)hipFree(t.block);
+            if (t.order_block) (void)hipFree(t.order_block);
+        }
         if (ctx->d_scene) (void)hipFree(ctx->d_scene);
         if (ctx->d_frame) (void)hipFree(ctx->d_frame);
         if (ctx->d_backproject) (void)hipFree(ctx->d_backproject);
@@ -861,6 +871,7 @@ static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tile
             for (size_t i = 1; i < ctx->tile_lists.size(); i++)
                 if (ctx->tile_lists[i].used < ctx->tile_lists[old].used) old = i;
             if (ctx->tile_lists[old].block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].block));   // (waits for the device)
+            if (ctx->tile_lists[old].order_block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].order_block));
             ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)old);
         }
         ctx->tile_lists.emplace_back();
@@ -884,7 +895,7 @@ struct rm_kernel_choice {
     rm_launch_mode mode;
     size_t lds_bytes = 0;
     int stack = 0, pow_mode = 0;
-    bool fast = false, staged = false, bvh = false, cull = false, edges = false, feedback = false;
+    bool fast = false, staged = false, bvh = false, cull = false, edges = false, order = false, feedback = false;
 };
 
 static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, rm_kernel_choice *k) {
@@ -922,7 +933,10 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     // RM_FEEDBACK=1 forces it for every launch of a kernel with the hierarchy walk, =0 switches it off.
     k->feedback = k->bvh && ctx->feedback_mode != 0 && !ctx->debug_empty &&
                   (ctx->feedback_mode == 1 || (p->max_depth >= 6u && tiles >= RM_FEEDBACK_MIN_TILES));
-    k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->feedback, st, pw);
+    // the patch-order feedback: launches of up to 4,096 patches that do not carry the tile-level feedback
+    k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE && tiles / 16u <= 4096u &&
+               (ctx->patch_order_mode == 1 || tiles >= RM_CLASSIFY_MIN_TILES);
+    k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order, k->feedback, st, pw);
     if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
     return RM_OK;
 }
@@ -1063,6 +1077,44 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             a.mask_exact = n_prims_all <= 64u ? 1u : 0u;
         }
     }
+    // Patch order (launches of up to 4,096 patches, without the tile-level feedback): the waves add their tiles' times to
+    // their patches' counters; the workgroup behind the classifying ones sorts the PREVIOUS launch's counters into the
+    // order the NEXT launch on this stream dispatches by: the patches that took longest first.  A 1080p launch is four
+    // tiles deep per wave slot and used to end with the top of the glass sphere -- 30 us tiles dispatched at 40 us of 78.
+    // Only the order of dispatch is carried over: every tile of every frame is rendered in full by the same code.
+    {
+        const uint32_t n_patches = a.n_tiles / 16u;
+        const bool reorder = k.order && per_wg == 1u;
+        if (reorder) {
+            rm_tile_lists *tl = nullptr;
+            rm_status ost = tile_lists_for(ctx, stream, a.n_tiles, &tl);
+            if (ost != RM_OK) return ost;
+            const uint64_t key[3] = {(uint64_t)a.n_tiles | ((uint64_t)p->frame_width << 32), (uint64_t)row_begin | ((uint64_t)band.stride << 32),
+                                     ctx->scene_epoch};
+            if (!tl->order_block || tl->order_cap < n_patches) {
+                if (tl->order_block) RM_HIP(ctx, hipFree(tl->order_block));     // (waits for the device)
+                tl->order_block = nullptr;
+                tl->order_cap = n_patches;
+                RM_HIP(ctx, hipMalloc(&tl->order_block, 4u * (size_t)n_patches * sizeof(uint32_t)));
+                tl->order_frames = 0;
+                tl->order_key[0] = ~0ull;
+            }
+            if (std::memcmp(tl->order_key, key, sizeof key) != 0) {             // another geometry or scene: start afresh
+                RM_HIP(ctx, hipMemsetAsync(tl->order_block, 0, 2u * (size_t)tl->order_cap * sizeof(uint32_t), stream));
+                std::memcpy(tl->order_key, key, sizeof key);
+                tl->order_frames = 0;
+            }
+            const uint32_t f = tl->order_frames++;
+            a.patch_cost = tl->cost(f & 1u);
+            if (f >= 1u) {                                                      // the previous launch's counters -> the next launch's order
+                a.sort_cost = tl->cost((f + 1u) & 1u);
+                a.sort_order = tl->order((f + 1u) & 1u);
+                a.sort_block = 1u;
+                grid.x += 1u;
+            }
+            if (f >= 2u) a.patch_order = tl->order(f & 1u);                     // sorted by the launch before from the counters of the one before that
+        }
+    }
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     unsigned long long *d_stamps = nullptr;
     const size_t n_waves = (size_t)grid.x * m.waves;
@@ -1188,9 +1240,9 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     st = choose_kernel(ctx, params, band.count() * (params->frame_width / RM_PATCH_SIZE) * 16u, &k);
     if (st != RM_OK) return st;
     // the name rocprofv3's kernel trace shows (template arguments in declaration order)
-    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
-                  k.cull ? "true" : "false", k.edges ? "true" : "false", k.feedback ? "true" : "false");
+                  k.cull ? "true" : "false", k.edges ? "true" : "false", k.order ? "true" : "false", k.feedback ? "true" : "false");
     return RM_OK;
 }
 

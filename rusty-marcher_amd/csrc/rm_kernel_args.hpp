@@ -78,6 +78,16 @@ struct KernelArgs {
     uint32_t mask_tag;
     uint32_t cls_blocks;
     uint32_t cls_prims;
+    // Patch order (rm_device.hip, launches of up to 4,096 patches without the tile-level feedback): every wave
+    // adds its tile's time to its 32x32 patch's counter; ONE workgroup at the head of the next launch on the
+    // stream sorts the patches by that (a counting sort over 64 buckets), and the launch after dispatches
+    // them longest first.  Only the order of dispatch is carried over.  NULL: off / no history yet.
+    const uint32_t *patch_order;             // this launch: the k-th 16 ids render patch patch_order[k]
+    uint32_t *patch_cost;                    // this launch adds here: 100 MHz ticks per patch
+    const uint32_t *sort_cost;               // the previous launch's counters: sorted into ...
+    uint32_t *sort_order;                    // ... the next launch's order by this launch's sorting workgroup, then cleared
+    uint32_t sort_block;                     // 1: the workgroup behind the classifying ones sorts
+    uint32_t _pad_order;
 };
 
 // What the classification launch gets besides the render launch's own arguments.
@@ -106,16 +116,18 @@ struct StackEntry {
 //   [480, 512)  the wave's hierarchy stack: 64 u32 entries
 //   [512, 704)  the tile's pixel sums, [pixel][channel] -- read as they lie by the store phase
 //   [704, 736)  pairing table of the ray hand-over: 64 u32 entries
+//   [736, 738)  the wave's start time (patch order)
 #define RM_WAVE_L0_DEPTH_WORDS 448u
 #define RM_WAVE_BVH_STACK_WORDS 480u
 #define RM_WAVE_SUM_WORDS 512u
 #define RM_WAVE_PAIR_WORDS 704u
-#define RM_WAVE_LDS_WORDS 736u
+#define RM_WAVE_T0_WORDS 736u      /* the wave's start time (patch order) */
+#define RM_WAVE_LDS_WORDS 738u
 
 }  // namespace rmdev
 
 // The kernel of a launch (rm_kernels.hip, compiled once per numeric flavour and kernel group):
 // stack 4 / 8 / 16 / 32, pow_mode POW_GENERIC / POW_INTEGER.  NULL: no such instantiation.
-const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool feedback, int stack, int pow_mode);
+const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool order, bool feedback, int stack, int pow_mode);
 
 #endif

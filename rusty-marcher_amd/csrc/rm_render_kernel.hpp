@@ -58,6 +58,11 @@ __device__ __forceinline__ uint32_t tile_of_id(const KernelArgs &a, uint32_t id)
          : (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
 }
 
+// ... or, with a patch order from the previous frames on the stream (rm_device.hip), the patches longest first
+__device__ __forceinline__ uint32_t tile_for(const KernelArgs &a, uint32_t id) {
+    return a.patch_order ? a.patch_order[id >> 4] * 16u + (15u - (id & 15u)) : tile_of_id(a, id);
+}
+
 // tile -> pixel origin.  Patch-major: patch = tile / 16 walks the band row by row
 // (renderer.rs:69-70), sub = tile % 16 walks the 4x4 tiles of the patch.
 __device__ __forceinline__ void tile_origin(const KernelArgs &a, uint32_t tile, uint32_t &tx0, uint32_t &ty0, uint32_t &tyf,

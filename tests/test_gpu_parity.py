@@ -740,6 +740,53 @@ def test_tile_classification_is_bitwise_invisible(pkg, O, monkeypatch):
         cls.close()
 
 
+def test_patch_order_renders_every_tile_once(pkg, monkeypatch):
+    """Patch order (rm_device.hip): every wave adds its tile's time to its patch's counter, one workgroup of the next
+    launch sorts the patches by that, and the launch after dispatches them longest first.  Only the ORDER of dispatch
+    may change: every frame of a sequence on one stream -- the same camera for several frames (counters, then an
+    order from them), a moved camera, another size, a band, another scene and back -- must equal the frame of a
+    context without it bit for bit, f64 and display bytes, in buffers pre-filled with a sentinel (a patch missing
+    from the order, or in it twice, would show)."""
+    import torch
+    monkeypatch.setenv("RM_PATCH_ORDER", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_PATCH_ORDER", "1")
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    ordered = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "0")
+    ordered_unclassified = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_TILE_CLASSIFY")
+    monkeypatch.delenv("RM_PATCH_ORDER")
+    demo = pkg.Scene.create_default()
+    cornell = workloads.product_scene(pkg, "cornell")
+    seq = [(demo, (0., 0., 0.), 640, 352, 5, None)] * 4 + [(demo, (0., 5., 0.), 640, 352, 5, None)] * 2 + \
+          [(demo, (0., 5., 0.), 800, 608, 4, None)] * 3 + [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 3 + \
+          [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 3 + [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 4
+    try:
+        for k, (scene, cam, w, h, depth, band) in enumerate(seq):
+            scene.camera = pkg.Vec3f(*cam)
+            p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
+            p.flags = _FLAGS["value"]
+            outs = []
+            for c in (plain, ordered, ordered_unclassified):
+                c.upload(scene.flatten())
+                f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+                u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+                torch.cuda.synchronize()
+                outs.append((f64.cpu().numpy(), u8.cpu().numpy()))
+            for j in (1, 2):
+                assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the patch order on (%d)" % (k, j)
+                assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
+            if band is None:
+                assert not (outs[1][0][:h // 32 * 32] == -1.).any()
+    finally:
+        plain.close()
+        ordered.close()
+        ordered_unclassified.close()
+
+
 def test_feedback_order_renders_every_tile_once(pkg, ctx, monkeypatch):
     """Frame-to-frame feedback (rm_device.hip, rm_feedback): the tiles that took long in the
     previous frame on a stream are dispatched first in the next.  Only the ORDER of dispatch may
