@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 3u
+#define RM_ABI_VERSION 4u
 
 typedef enum rm_status {
     RM_OK = 0,
@@ -311,6 +311,14 @@ rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device
  * small frames, scenes of many primitives).  hip_stream: the stream that launch was enqueued on (NULL: whichever
  * the context's last render launch went to).  Waits for the device. */
 rm_status rm_tile_stats(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t *tiles_listed);
+
+/* The geometry of the context's last render launch: its workgroups (one wave each), and how many 32x32 patches of
+ * it were handed to its sky tail -- patches that the previous frames of the same view on the stream found nothing to
+ * hit in get ONE wave instead of sixteen (it looks at this launch's own classification of the patch, stores the
+ * primary-miss value of renderer.rs:305 over the patch when that still says sky, and renders the patch itself when
+ * it does not).  Only the launch's geometry is carried from frame to frame; RM_SKY_TAIL=0 switches it off.
+ * Does not wait for the device. */
+rm_status rm_launch_stats(rm_ctx *ctx, uint32_t *workgroups, uint32_t *tail_patches);
 
 /* Device framebuffer of the last rm_render(.., NULL, ..) and its size in bytes. */
 rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes);

@@ -116,6 +116,7 @@ SIGNATURES = {
     "rm_render_device": (C.c_int, [_VP, _P(rm_params), _VP, _VP]),
     "rm_render_device_u8": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP]),
     "rm_tile_stats": (C.c_int, [_VP, _VP, _P(C.c_uint32), _P(C.c_uint32)]),
+    "rm_launch_stats": (C.c_int, [_VP, _P(C.c_uint32), _P(C.c_uint32)]),
     "rm_device_framebuffer": (C.c_int, [_VP, _P(_VP), _P(C.c_size_t)]),
     "rm_postprocess": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_int, _P(C.c_uint8), _P(C.c_double)]),
     "rm_buffer_alloc": (C.c_int, [_VP, C.c_size_t, _P(_VP)]),

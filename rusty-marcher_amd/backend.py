@@ -78,6 +78,12 @@ class Context:
         _lib.check(self.L.rm_tile_stats(self.ptr, C.c_void_p(stream) if stream else None, C.byref(a), C.byref(b)), self.ptr)
         return a.value, b.value
 
+    def launch_stats(self):
+        """(workgroups of the last render launch, patches handed to its sky tail)"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(self.L.rm_launch_stats(self.ptr, C.byref(a), C.byref(b)), self.ptr)
+        return a.value, b.value
+
     def hostio_stats(self):
         """What the last host-bound call moved: bytes over the link, patches, patches sent, threads."""
         b, p, s, t = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)

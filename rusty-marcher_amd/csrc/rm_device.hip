@@ -154,6 +154,11 @@ struct rm_tile_lists {
     uint64_t order_key[3] = {0, 0, 0};
     uint32_t *cost(uint32_t j) const { return static_cast<uint32_t *>(order_block) + (size_t)j * order_cap; }
     uint32_t *order(uint32_t j) const { return static_cast<uint32_t *>(order_block) + (size_t)(2u + j) * order_cap; }
+    // sky tail: the sorter's word in page-locked memory -- (launch seq << 32) | patches with something to hit --, the
+    // launches on this stream counted, the first launch of the view being rendered, and that view
+    unsigned long long *hint = nullptr;
+    uint32_t seq = 0, view_seq0 = 0;
+    double view[7] = {0., 0., 0., 0., 0., 0., 0.};
     // classification at the head of the render launch: the words carry the launch's tag (1..255)
     uint32_t tag = 0, tagged_tiles = 0;
     uint64_t tagged_scene = 0;
@@ -207,8 +212,11 @@ struct rm_ctx {
     // launches of RM_CLASSIFY_MIN_TILES tiles and more
     int classify_mode = -1;
     bool classify_in_launch = true;      // RM_CLASSIFY_IN_LAUNCH=0: always a launch of its own in front (A/B knob)
+    bool sky_tail = true;                // RM_SKY_TAIL=0: every patch gets its sixteen waves
+    int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
     int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
     std::vector<rm_tile_lists> tile_lists;
+    uint32_t last_launch_grid = 0, last_launch_tail = 0;   // rm_launch_stats
     uint32_t last_launch_tiles = 0;   // rm_tile_stats: the last render launch's tiles, and whether they were classified
     bool last_launch_classified = false;
     hipStream_t last_launch_stream = nullptr;
@@ -300,7 +308,7 @@ const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edg
 extern "C" {
 
 const char *rm_build_info(void) {
-    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi3";
+    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi4";
 }
 
 const char *rm_last_error(const rm_ctx *ctx) {
@@ -349,6 +357,8 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_TILE_CLASSIFY")) ctx->classify_mode = env[0] == '1' ? 1 : 0;
     if (const char *env = std::getenv("RM_CLASSIFY_IN_LAUNCH")) ctx->classify_in_launch = env[0] == '1';
     if (const char *env = std::getenv("RM_PATCH_ORDER")) ctx->patch_order_mode = env[0] == '1' ? 1 : 0;
+    if (const char *env = std::getenv("RM_SKY_TAIL")) ctx->sky_tail = env[0] != '0';
+    if (const char *env = std::getenv("RM_SKY_TAIL_FORCE")) ctx->sky_tail_force = std::atoi(env);
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
@@ -386,6 +396,7 @@ void rm_destroy(rm_ctx *ctx) {
         for (rm_tile_lists &t : ctx->tile_lists) {
             if (t.block) (void)hipFree(t.block);
             if (t.order_block) (void)hipFree(t.order_block);
+            if (t.hint) (void)hipHostFree(t.hint);
         }
         if (ctx->d_scene) (void)hipFree(ctx->d_scene);
         if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -872,6 +883,7 @@ static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tile
                 if (ctx->tile_lists[i].used < ctx->tile_lists[old].used) old = i;
             if (ctx->tile_lists[old].block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].block));   // (waits for the device)
             if (ctx->tile_lists[old].order_block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].order_block));
+            if (ctx->tile_lists[old].hint) RM_HIP(ctx, hipHostFree(ctx->tile_lists[old].hint));
             ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)old);
         }
         ctx->tile_lists.emplace_back();
@@ -1113,6 +1125,42 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 grid.x += 1u;
             }
             if (f >= 2u) a.patch_order = tl->order(f & 1u);                     // sorted by the launch before from the counters of the one before that
+            // Sky tail.  The head of every launch marks the patches nothing can be hit in, the sorter puts them last and
+            // writes how many the others are into page-locked memory.  While the VIEW is the one those frames had, the sky
+            // patches at the end of the order get one wave each instead of sixteen (the dispatcher takes ~0.7 ns per wave
+            // that looks at its word, stores its zeros and leaves: half of a Cornell launch).  Only the launch's geometry is
+            // carried over: each of those waves looks at THIS launch's classification of its patch and renders it where it
+            // is not sky after all.
+            if (!tl->hint) {
+                RM_HIP(ctx, hipHostMalloc((void **)&tl->hint, sizeof(unsigned long long), hipHostMallocDefault));
+                *tl->hint = 0ull;
+            }
+            const uint32_t seq = ++tl->seq;
+            const double view[7] = {ctx->camera.x, ctx->camera.y, ctx->camera.z, p->half_fov, p->height, p->width, p->ratio};
+            if (f == 0u || std::memcmp(tl->view, view, sizeof view) != 0) {
+                std::memcpy(tl->view, view, sizeof view);
+                tl->view_seq0 = seq;
+            }
+            a.sort_hint = tl->hint;
+            a.launch_seq = seq;
+            if (ctx->sky_tail && a.cls_blocks && a.patch_order) {
+                uint32_t tail = 0;
+                if (ctx->sky_tail_force >= 0) {                                 // (test hook: a hint that is wrong)
+                    tail = std::min((uint32_t)ctx->sky_tail_force, n_patches);
+                } else if (seq >= tl->view_seq0 + 2u) {
+                    // (the order in use was sorted from the frame two launches back, the hint from the frame before its
+                    // sorter's launch: both must be frames of this view)
+                    const unsigned long long h = *(volatile unsigned long long *)tl->hint;
+                    const uint32_t h_seq = (uint32_t)(h >> 32), n_lit = (uint32_t)h;
+                    if (h_seq >= tl->view_seq0 + 1u && h_seq < seq && n_lit <= n_patches) tail = n_patches - n_lit;
+                    if (tail < 8u) tail = 0u;
+                }
+                a.tail_patches = tail;
+                grid.x -= 15u * tail;
+                // (dealt out evenly among the tile waves behind the launch's first round: rm_render_kernel.inc)
+                const uint64_t head_ids = a.n_tiles - 16u * tail, behind = head_ids - std::min<uint64_t>(4096u, head_ids);
+                a.tail_q = (tail && behind) ? (uint32_t)((((uint64_t)tail << 32) + behind + tail - 1u) / (behind + tail)) : 0u;
+            }
         }
     }
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
@@ -1124,10 +1172,13 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
 #endif
     void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
+    ctx->last_launch_grid = grid.x;
+    ctx->last_launch_tail = a.tail_patches;
     if (fb) fb->cur = (fb->cur + 1) % 3;
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     RM_HIP(ctx, hipStreamSynchronize(stream));
     if (const char *path = std::getenv("RM_DEBUG_STAMPS")) {
+        std::fprintf(stderr, "stamps: grid %u cls_blocks %u sort_block %u n_tiles %u tail_patches %u tail_q %u\n", grid.x, a.cls_blocks, a.sort_block, a.n_tiles, a.tail_patches, a.tail_q);
         std::vector<unsigned long long> h(n_waves * 4);
         RM_HIP(ctx, hipMemcpy(h.data(), d_stamps, n_waves * 32, hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
@@ -1243,6 +1294,13 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
                   k.cull ? "true" : "false", k.edges ? "true" : "false", k.order ? "true" : "false", k.feedback ? "true" : "false");
+    return RM_OK;
+}
+
+rm_status rm_launch_stats(rm_ctx *ctx, uint32_t *workgroups, uint32_t *tail_patches) {
+    if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_launch_stats: NULL ctx");
+    if (workgroups) *workgroups = ctx->last_launch_grid;
+    if (tail_patches) *tail_patches = ctx->last_launch_tail;
     return RM_OK;
 }
 

@@ -87,7 +87,15 @@ struct KernelArgs {
     const uint32_t *sort_cost;               // the previous launch's counters: sorted into ...
     uint32_t *sort_order;                    // ... the next launch's order by this launch's sorting workgroup, then cleared
     uint32_t sort_block;                     // 1: the workgroup behind the classifying ones sorts
-    uint32_t _pad_order;
+    // Sky tail: the classification at the head of a launch marks the patches nothing can be hit in (bit 31 of their
+    // counters), the sorter puts them last and tells the host how many the others are (page-locked memory: a hint, read
+    // without a wait); while the view stays the same the next launches give the last tail_patches patches of the order
+    // ONE wave each, which looks at this launch's own classification: sky -> 24 KB of zeros; not sky (a stale hint) ->
+    // the wave renders the patch's sixteen tiles itself.  0: every patch gets its sixteen waves.
+    uint32_t tail_patches;
+    unsigned long long *sort_hint;           // (launch_seq << 32) | patches with something to hit, written by the sorter
+    uint32_t launch_seq;
+    uint32_t tail_q;                         // ceil(tail_patches 2^32 / (tail_patches + tile waves behind the first round)), 0: no such waves
 };
 
 // What the classification launch gets besides the render launch's own arguments.

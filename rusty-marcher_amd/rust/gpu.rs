@@ -146,6 +146,7 @@ extern "C" {
     fn rm_render_device(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, hip_stream: *mut c_void) -> c_int;
     fn rm_render_device_u8(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_rgb8: *mut c_void, hip_stream: *mut c_void) -> c_int;
     fn rm_tile_stats(ctx: *mut RmCtx, hip_stream: *mut c_void, tiles: *mut u32, tiles_listed: *mut u32) -> c_int;
+    fn rm_launch_stats(ctx: *mut RmCtx, workgroups: *mut u32, tail_patches: *mut u32) -> c_int;
     fn rm_device_framebuffer(ctx: *mut RmCtx, device_rgb: *mut *mut c_void, bytes: *mut usize) -> c_int;
     fn rm_postprocess(ctx: *mut RmCtx, device_rgb: *mut c_void, frame_width: u32, frame_height: u32, normalize: c_int, host_rgb8: *mut u8, max_out: *mut f64) -> c_int;
     // interactive loop / several GPUs (one process per GPU): host/rm_walk.cpp is the same

@@ -787,6 +787,68 @@ def test_patch_order_renders_every_tile_once(pkg, monkeypatch):
         ordered_unclassified.close()
 
 
+def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
+    """Sky tail (rm_device.hip): patches that the previous frames of a view found nothing to hit in get one wave instead
+    of sixteen; that wave looks at THIS launch's classification of its patch, stores the primary-miss value when it
+    still says sky and renders the patch itself when it does not.  Only the launch's geometry may be carried over: every
+    frame of a sequence on one stream -- a view held for several frames (the tail arms itself), a moved camera, bands,
+    display bytes, another scene -- must equal the frame of a context without it bit for bit in buffers pre-filled
+    with a sentinel; so must the frames of contexts whose hint is WRONG (RM_SKY_TAIL_FORCE: the last 37 patches of the
+    order, or every patch, taken for sky whatever the classification of the earlier frames said)."""
+    import torch
+    monkeypatch.setenv("RM_PATCH_ORDER", "1")
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    monkeypatch.setenv("RM_SKY_TAIL", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL", "1")
+    tail = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL_FORCE", "37")
+    wrong_some = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL_FORCE", "100000")
+    wrong_all = pkg.backend.Context(0)
+    for v in ("RM_SKY_TAIL_FORCE", "RM_SKY_TAIL", "RM_TILE_CLASSIFY", "RM_PATCH_ORDER"):
+        monkeypatch.delenv(v)
+    demo = pkg.Scene.create_default()
+    cornell = workloads.product_scene(pkg, "cornell")
+    seq = [(demo, (0., 0., 0.), 640, 352, 5, None)] * 6 + [(demo, (0., 5., 0.), 640, 352, 5, None)] * 5 + \
+          [(demo, (0., 5. + k, -2. * k), 640, 352, 5, None) for k in range(4)] + \
+          [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 5 + [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 6 + \
+          [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 5
+    armed = {"tail": 0, "wrong_some": 0, "wrong_all": 0}
+    try:
+        for k, (scene, cam, w, h, depth, band) in enumerate(seq):
+            scene.camera = pkg.Vec3f(*cam)
+            p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
+            p.flags = _FLAGS["value"]
+            outs = []
+            for name, c in (("plain", plain), ("tail", tail), ("wrong_some", wrong_some), ("wrong_all", wrong_all)):
+                if os.environ.get("RM_TEST_TRACE"):
+                    print("frame", k, name, cam, w, h, depth, band, flush=True)
+                c.upload(scene.flatten())
+                f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+                u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+                torch.cuda.synchronize()
+                outs.append((f64.cpu().numpy(), u8.cpu().numpy()))
+                grid, n_tail = c.launch_stats()
+                if name == "plain":
+                    assert n_tail == 0
+                else:
+                    armed[name] += n_tail > 0
+            for j in (1, 2, 3):
+                assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the sky tail on (%d)" % (k, j)
+                assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
+            if band is None:
+                assert not (outs[1][0][:h // 32 * 32] == -1.).any()
+        # the tail armed itself where a view was held, and the wrong hints were in force
+        assert armed["tail"] >= 8, armed
+        assert armed["wrong_some"] >= 15 and armed["wrong_all"] >= 15, armed
+    finally:
+        for c in (plain, tail, wrong_some, wrong_all):
+            c.close()
+
+
 def test_feedback_order_renders_every_tile_once(pkg, ctx, monkeypatch):
     """Frame-to-frame feedback (rm_device.hip, rm_feedback): the tiles that took long in the
     previous frame on a stream are dispatched first in the next.  Only the ORDER of dispatch may
