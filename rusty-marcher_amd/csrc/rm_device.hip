@@ -213,6 +213,8 @@ struct rm_ctx {
     int classify_mode = -1;
     bool classify_in_launch = true;      // RM_CLASSIFY_IN_LAUNCH=0: always a launch of its own in front (A/B knob)
     bool sky_tail = true;                // RM_SKY_TAIL=0: every patch gets its sixteen waves
+    uint32_t patch_order_max = 4096;     // RM_PATCH_ORDER_MAX: launches of up to this many patches take the kernels with the patch order
+    int sky_tail_keep = 128;               // RM_SKY_TAIL_KEEP=n: the last n sky patches of the order keep their sixteen waves
     int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
     int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
     std::vector<rm_tile_lists> tile_lists;
@@ -359,6 +361,8 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_PATCH_ORDER")) ctx->patch_order_mode = env[0] == '1' ? 1 : 0;
     if (const char *env = std::getenv("RM_SKY_TAIL")) ctx->sky_tail = env[0] != '0';
     if (const char *env = std::getenv("RM_SKY_TAIL_FORCE")) ctx->sky_tail_force = std::atoi(env);
+    if (const char *env = std::getenv("RM_PATCH_ORDER_MAX")) ctx->patch_order_max = (uint32_t)std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_SKY_TAIL_KEEP")) ctx->sky_tail_keep = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
@@ -946,7 +950,7 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     k->feedback = k->bvh && ctx->feedback_mode != 0 && !ctx->debug_empty &&
                   (ctx->feedback_mode == 1 || (p->max_depth >= 6u && tiles >= RM_FEEDBACK_MIN_TILES));
     // the patch-order feedback: launches of up to 4,096 patches that do not carry the tile-level feedback
-    k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE && tiles / 16u <= 4096u &&
+    k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE && tiles / 16u <= ctx->patch_order_max &&
                (ctx->patch_order_mode == 1 || tiles >= RM_CLASSIFY_MIN_TILES);
     k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order, k->feedback, st, pw);
     if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
@@ -1144,7 +1148,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             a.sort_hint = tl->hint;
             a.launch_seq = seq;
             if (ctx->sky_tail && a.cls_blocks && a.patch_order) {
-                uint32_t tail = 0;
+                uint32_t tail = 0, keep = 0;
                 if (ctx->sky_tail_force >= 0) {                                 // (test hook: a hint that is wrong)
                     tail = std::min((uint32_t)ctx->sky_tail_force, n_patches);
                 } else if (seq >= tl->view_seq0 + 2u) {
@@ -1153,9 +1157,13 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                     const unsigned long long h = *(volatile unsigned long long *)tl->hint;
                     const uint32_t h_seq = (uint32_t)(h >> 32), n_lit = (uint32_t)h;
                     if (h_seq >= tl->view_seq0 + 1u && h_seq < seq && n_lit <= n_patches) tail = n_patches - n_lit;
+                    // (the last sky patches keep their sixteen waves: short waves that fill the launch's drain)
+                    tail -= std::min(tail, (uint32_t)ctx->sky_tail_keep);
                     if (tail < 8u) tail = 0u;
+                    keep = (n_patches - n_lit) - tail;
                 }
                 a.tail_patches = tail;
+                a.tail_first = n_patches - tail - (tail ? keep : 0u);
                 grid.x -= 15u * tail;
                 // (dealt out evenly among the tile waves behind the launch's first round: rm_render_kernel.inc)
                 const uint64_t head_ids = a.n_tiles - 16u * tail, behind = head_ids - std::min<uint64_t>(4096u, head_ids);

@@ -93,6 +93,8 @@ struct KernelArgs {
     // ONE wave each, which looks at this launch's own classification: sky -> 24 KB of zeros; not sky (a stale hint) ->
     // the wave renders the patch's sixteen tiles itself.  0: every patch gets its sixteen waves.
     uint32_t tail_patches;
+    uint32_t tail_first;                     // the tail: patches [tail_first, tail_first + tail_patches) of the order (sky patches behind it keep their sixteen waves: they fill the launch's drain)
+    uint32_t _pad_tail;
     unsigned long long *sort_hint;           // (launch_seq << 32) | patches with something to hit, written by the sorter
     uint32_t launch_seq;
     uint32_t tail_q;                         // ceil(tail_patches 2^32 / (tail_patches + tile waves behind the first round)), 0: no such waves

@@ -60,7 +60,10 @@ __device__ __forceinline__ uint32_t tile_of_id(const KernelArgs &a, uint32_t id)
 
 // ... or, with a patch order from the previous frames on the stream (rm_device.hip), the patches longest first
 __device__ __forceinline__ uint32_t tile_for(const KernelArgs &a, uint32_t id) {
-    return a.patch_order ? a.patch_order[id >> 4] * 16u + (15u - (id & 15u)) : tile_of_id(a, id);
+    // (sky tail: the patches [tail_first, tail_first + tail_patches) of the order are not these waves')
+    uint32_t k = id >> 4;
+    k += (a.tail_patches && k >= a.tail_first) ? a.tail_patches : 0u;
+    return a.patch_order ? a.patch_order[k] * 16u + (15u - (id & 15u)) : tile_of_id(a, id);
 }
 
 // tile -> pixel origin.  Patch-major: patch = tile / 16 walks the band row by row

@@ -801,12 +801,15 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     monkeypatch.setenv("RM_SKY_TAIL", "0")
     plain = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL", "1")
+    monkeypatch.setenv("RM_SKY_TAIL_KEEP", "0")                     # (frames of a few hundred patches: every sky patch to the tail)
     tail = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL_KEEP", "16")                    # (the last sixteen sky patches keep their sixteen waves)
+    tail_keep = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "37")
     wrong_some = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "100000")
     wrong_all = pkg.backend.Context(0)
-    for v in ("RM_SKY_TAIL_FORCE", "RM_SKY_TAIL", "RM_TILE_CLASSIFY", "RM_PATCH_ORDER"):
+    for v in ("RM_SKY_TAIL_FORCE", "RM_SKY_TAIL_KEEP", "RM_SKY_TAIL", "RM_TILE_CLASSIFY", "RM_PATCH_ORDER"):
         monkeypatch.delenv(v)
     demo = pkg.Scene.create_default()
     cornell = workloads.product_scene(pkg, "cornell")
@@ -814,14 +817,14 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
           [(demo, (0., 5. + k, -2. * k), 640, 352, 5, None) for k in range(4)] + \
           [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 5 + [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 6 + \
           [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 5
-    armed = {"tail": 0, "wrong_some": 0, "wrong_all": 0}
+    armed = {"tail": 0, "tail_keep": 0, "wrong_some": 0, "wrong_all": 0}
     try:
         for k, (scene, cam, w, h, depth, band) in enumerate(seq):
             scene.camera = pkg.Vec3f(*cam)
             p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
             p.flags = _FLAGS["value"]
             outs = []
-            for name, c in (("plain", plain), ("tail", tail), ("wrong_some", wrong_some), ("wrong_all", wrong_all)):
+            for name, c in (("plain", plain), ("tail", tail), ("tail_keep", tail_keep), ("wrong_some", wrong_some), ("wrong_all", wrong_all)):
                 if os.environ.get("RM_TEST_TRACE"):
                     print("frame", k, name, cam, w, h, depth, band, flush=True)
                 c.upload(scene.flatten())
@@ -836,16 +839,16 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
                     assert n_tail == 0
                 else:
                     armed[name] += n_tail > 0
-            for j in (1, 2, 3):
+            for j in (1, 2, 3, 4):
                 assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the sky tail on (%d)" % (k, j)
                 assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
             if band is None:
                 assert not (outs[1][0][:h // 32 * 32] == -1.).any()
         # the tail armed itself where a view was held, and the wrong hints were in force
-        assert armed["tail"] >= 8, armed
+        assert armed["tail"] >= 8 and armed["tail_keep"] >= 8, armed
         assert armed["wrong_some"] >= 15 and armed["wrong_all"] >= 15, armed
     finally:
-        for c in (plain, tail, wrong_some, wrong_all):
+        for c in (plain, tail, tail_keep, wrong_some, wrong_all):
             c.close()
 
 
