@@ -214,6 +214,8 @@ struct rm_ctx {
     bool classify_in_launch = true;      // RM_CLASSIFY_IN_LAUNCH=0: always a launch of its own in front (A/B knob)
     bool sky_tail = true;                // RM_SKY_TAIL=0: every patch gets its sixteen waves
     uint32_t patch_order_max = 4096;     // RM_PATCH_ORDER_MAX: launches of up to this many patches take the kernels with the patch order
+    uint32_t sky_tail_big_min = 16384;   // RM_SKY_TAIL_BIG_MIN (patches; see RM_SKY_TAIL_BIG_MIN_PATCHES)
+    bool sky_tail_big = true;            // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
     int sky_tail_keep = 128;               // RM_SKY_TAIL_KEEP=n: the last n sky patches of the order keep their sixteen waves
     int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
     int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
@@ -362,6 +364,8 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_SKY_TAIL")) ctx->sky_tail = env[0] != '0';
     if (const char *env = std::getenv("RM_SKY_TAIL_FORCE")) ctx->sky_tail_force = std::atoi(env);
     if (const char *env = std::getenv("RM_PATCH_ORDER_MAX")) ctx->patch_order_max = (uint32_t)std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_SKY_TAIL_BIG")) ctx->sky_tail_big = env[0] != '0';
+    if (const char *env = std::getenv("RM_SKY_TAIL_BIG_MIN")) ctx->sky_tail_big_min = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_KEEP")) ctx->sky_tail_keep = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -871,6 +875,10 @@ static rm_status feedback_for(rm_ctx *ctx, hipStream_t stream, const uint64_t ke
 }
 
 static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 8192, RM_CLASSIFY_STREAMS = 8;
+// Launches of this many patches and more take the kernels with the patch order for the sky tail alone (order_by_place):
+// measured 8K 987 -> 960 us; at 4K (8,100 patches) the sorting workgroup and the order's indirection cost what the tail saves
+// (245.3 against 243.8 us).
+static constexpr uint32_t RM_SKY_TAIL_BIG_MIN_PATCHES = 16384;   // (rm_ctx::sky_tail_big_min)
 // What a lane of the classification spends on its share of a patch's primitives, in vector instructions: ~22
 // per bounding sphere, ~110 more for the edge and plane tests of a planar primitive.  Beyond this the launch
 // is not worth its time.
@@ -950,7 +958,9 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     k->feedback = k->bvh && ctx->feedback_mode != 0 && !ctx->debug_empty &&
                   (ctx->feedback_mode == 1 || (p->max_depth >= 6u && tiles >= RM_FEEDBACK_MIN_TILES));
     // the patch-order feedback: launches of up to 4,096 patches that do not carry the tile-level feedback
-    k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE && tiles / 16u <= ctx->patch_order_max &&
+    // (launches of more patches than that take the same kernels for the sky tail alone: by_place, below)
+    k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE &&
+               (tiles / 16u <= ctx->patch_order_max || (ctx->sky_tail && ctx->sky_tail_big && n_prims <= 56u && tiles / 16u >= ctx->sky_tail_big_min)) &&
                (ctx->patch_order_mode == 1 || tiles >= RM_CLASSIFY_MIN_TILES);
     k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order, k->feedback, st, pw);
     if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
@@ -1147,6 +1157,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             }
             a.sort_hint = tl->hint;
             a.launch_seq = seq;
+            a.order_by_place = n_patches > ctx->patch_order_max ? 1u : 0u;
             if (ctx->sky_tail && a.cls_blocks && a.patch_order) {
                 uint32_t tail = 0, keep = 0;
                 if (ctx->sky_tail_force >= 0) {                                 // (test hook: a hint that is wrong)

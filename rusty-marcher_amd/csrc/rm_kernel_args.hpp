@@ -14,6 +14,10 @@
 #ifndef RM_MIN_WAVES
 #define RM_MIN_WAVES 4
 #endif
+// ... and the kernels with the cull's edge test (at 4 they spill 19 values around the cull step)
+#ifndef RM_EDGES_WAVES
+#define RM_EDGES_WAVES 3
+#endif
 
 namespace rmdev {
 
@@ -94,7 +98,7 @@ struct KernelArgs {
     // the wave renders the patch's sixteen tiles itself.  0: every patch gets its sixteen waves.
     uint32_t tail_patches;
     uint32_t tail_first;                     // the tail: patches [tail_first, tail_first + tail_patches) of the order (sky patches behind it keep their sixteen waves: they fill the launch's drain)
-    uint32_t _pad_tail;
+    uint32_t order_by_place;                 // launches of more than 4,096 patches: no tile is timed, the order is bottom-up less the sky (which goes to the tail)
     unsigned long long *sort_hint;           // (launch_seq << 32) | patches with something to hit, written by the sorter
     uint32_t launch_seq;
     uint32_t tail_q;                         // ceil(tail_patches 2^32 / (tail_patches + tile waves behind the first round)), 0: no such waves

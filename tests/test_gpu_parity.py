@@ -805,6 +805,11 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     tail = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL_KEEP", "16")                    # (the last sixteen sky patches keep their sixteen waves)
     tail_keep = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_PATCH_ORDER_MAX", "100")                 # (larger launches: no tile is timed, the order is bottom-up less the sky)
+    monkeypatch.setenv("RM_SKY_TAIL_BIG_MIN", "0")
+    by_place = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_PATCH_ORDER_MAX")
+    monkeypatch.delenv("RM_SKY_TAIL_BIG_MIN")
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "37")
     wrong_some = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "100000")
@@ -817,14 +822,15 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
           [(demo, (0., 5. + k, -2. * k), 640, 352, 5, None) for k in range(4)] + \
           [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 5 + [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 6 + \
           [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 5
-    armed = {"tail": 0, "tail_keep": 0, "wrong_some": 0, "wrong_all": 0}
+    armed = {"tail": 0, "tail_keep": 0, "by_place": 0, "wrong_some": 0, "wrong_all": 0}
     try:
         for k, (scene, cam, w, h, depth, band) in enumerate(seq):
             scene.camera = pkg.Vec3f(*cam)
             p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
             p.flags = _FLAGS["value"]
             outs = []
-            for name, c in (("plain", plain), ("tail", tail), ("tail_keep", tail_keep), ("wrong_some", wrong_some), ("wrong_all", wrong_all)):
+            for name, c in (("plain", plain), ("tail", tail), ("tail_keep", tail_keep), ("by_place", by_place), ("wrong_some", wrong_some),
+                            ("wrong_all", wrong_all)):
                 if os.environ.get("RM_TEST_TRACE"):
                     print("frame", k, name, cam, w, h, depth, band, flush=True)
                 c.upload(scene.flatten())
@@ -839,16 +845,16 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
                     assert n_tail == 0
                 else:
                     armed[name] += n_tail > 0
-            for j in (1, 2, 3, 4):
+            for j in (1, 2, 3, 4, 5):
                 assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the sky tail on (%d)" % (k, j)
                 assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
             if band is None:
                 assert not (outs[1][0][:h // 32 * 32] == -1.).any()
         # the tail armed itself where a view was held, and the wrong hints were in force
-        assert armed["tail"] >= 8 and armed["tail_keep"] >= 8, armed
+        assert armed["tail"] >= 8 and armed["tail_keep"] >= 8 and armed["by_place"] >= 8, armed
         assert armed["wrong_some"] >= 15 and armed["wrong_all"] >= 15, armed
     finally:
-        for c in (plain, tail, tail_keep, wrong_some, wrong_all):
+        for c in (plain, tail, tail_keep, by_place, wrong_some, wrong_all):
             c.close()
 
 
@@ -1263,6 +1269,7 @@ def test_render_device_into_torch_buffer(pkg, O, ctx):
     w, h = 640, 352
     ctx.upload(pkg.Scene.create_default().flatten())
     buf = torch.full((h, w, 3), -3., dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()                                               # (the fill runs on torch's default stream, the render on another)
     stream = torch.cuda.Stream()
     p = pkg.backend.make_params(1.5, float(h), float(w), 5, band=(2, 9))
     with torch.cuda.stream(stream):
@@ -1285,6 +1292,7 @@ def test_render_device_u8_display_bytes(pkg, O, ctx):
     u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
     p = pkg.backend.make_params(1.5, float(h), float(w), depth, band=(1, 10))
     p.flags = _FLAGS["value"]
+    torch.cuda.synchronize()                                               # (the fills run on torch's default stream, the render on another)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx.render_device_u8(p, f64.data_ptr(), u8.data_ptr(), stream.cuda_stream)
