@@ -554,6 +554,10 @@ def rank_main(args):
 
         def fence(direct=False):
             drain(direct)
+            # (a host thread that blocks in the wait wakes up a scheduler tick late on a busy box -- 5 ms were read once
+            # on 14 ms of launches: the stream is polled first, the wait then returns at once)
+            while not stream.query():
+                pass
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -582,6 +586,7 @@ def rank_main(args):
             # HIP events on the launch stream bracket the timed region (one pair: an event per
             # launch would put two extra packets between consecutive kernels)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream); ev1.record(stream)      # (torch creates an event when it is first recorded: not inside the bracket)
             fence(direct)
             t0 = time.perf_counter()
             ev0.record(stream)
