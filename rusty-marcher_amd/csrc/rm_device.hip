@@ -874,7 +874,10 @@ static rm_status feedback_for(rm_ctx *ctx, hipStream_t stream, const uint64_t ke
     return RM_OK;
 }
 
-static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 8192, RM_CLASSIFY_STREAMS = 8;
+// (launches of more than one round of wave slots -- 4,096 -- and a little: with the patches sorted by their longest tile the order
+// pays from there on: 640x480, 4,800 tiles, 35.9 -> 31.9 us, 800x600 34.1 -> 31.0, a quarter of a 1080p frame 44.4 -> 34.8;
+// 320x240, 1,120 tiles, which all start at once: 18.0 -> 19.3, left alone)
+static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 4608, RM_CLASSIFY_STREAMS = 8;
 // Launches of this many patches and more take the kernels with the patch order for the sky tail alone (order_by_place):
 // measured 8K 987 -> 960 us; at 4K (8,100 patches) the sorting workgroup and the order's indirection cost what the tail saves
 // (245.3 against 243.8 us).

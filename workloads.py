@@ -29,6 +29,8 @@ CONFIGS = {
     "C2_4K": dict(scene="demo", width=3840, height=2160, max_depth=5),     # north star's 4K point (C2 at 4K)
     "C5": dict(scene="synthetic256", width=4096, height=4096, max_depth=10),
     "QHD": dict(scene="demo", width=2560, height=1440, max_depth=5),          # between 1080p and 4K
+    "VGA": dict(scene="demo", width=640, height=480, max_depth=5),            # 4,800 tiles: a little more than one round of wave slots
+    "SVGA": dict(scene="demo", width=800, height=608, max_depth=5),           # 7,600 tiles
     "C2_5K": dict(scene="demo", width=5120, height=2880, max_depth=5),
     # the reference's own operating points (depth cap 3, renderer.rs:262)
     "REF800": dict(scene="demo", width=800, height=600, max_depth=3),      # engine/out.ppm
