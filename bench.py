@@ -592,9 +592,13 @@ def rank_main(args):
             ev0.record(stream)
             for _ in range(steps):
                 step()
+            t_enq = time.perf_counter()
             ev1.record(stream)
             fence(direct)
             elapsed = time.perf_counter() - t0
+            if os.environ.get("RM_BENCH_TRACE"):
+                sys.stderr.write("[bench] bracket: %d steps, wall %.1f us, enqueued after %.1f us, events %.1f us\n"
+                                 % (steps, elapsed * 1e6, (t_enq - t0) * 1e6, ev0.elapsed_time(ev1) * 1e3))
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             if use_dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
