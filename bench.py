@@ -749,8 +749,9 @@ def rank_main(args):
             pf = [torch.zeros((h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_slots)]
             pg = [torch.zeros((n_rows * 32, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)]
             n_frames = max(steps, 30)
-            for k in range(n_slots * 4 + n_frames):
-                if k == n_slots * 4:
+            n_warm = n_slots * 10                        # (each slot's stream needs a few frames of its own: patch order, sky tail)
+            for k in range(n_warm + n_frames):
+                if k == n_warm:
                     for b in range(n_slots):
                         ctx.frame_wait(b)
                     t1 = time.perf_counter()
