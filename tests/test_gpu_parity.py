@@ -803,8 +803,10 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     monkeypatch.setenv("RM_SKY_TAIL", "1")
     monkeypatch.setenv("RM_SKY_TAIL_KEEP", "0")                     # (frames of a few hundred patches: every sky patch to the tail)
     tail = pkg.backend.Context(0)
-    monkeypatch.setenv("RM_SKY_TAIL_KEEP", "16")                    # (the last sixteen sky patches keep their sixteen waves)
+    monkeypatch.setenv("RM_SKY_TAIL_KEEP", "16")                    # (the last sixteen sky patches keep their sixteen waves,
+    monkeypatch.setenv("RM_SKY_TAIL_PLACE", "even")                 # the tail's waves dealt out among the tile waves, not behind them)
     tail_keep = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_SKY_TAIL_PLACE")
     monkeypatch.setenv("RM_PATCH_ORDER_MAX", "100")                 # (larger launches: no tile is timed, the order is bottom-up less the sky)
     monkeypatch.setenv("RM_SKY_TAIL_BIG_MIN", "0")
     by_place = pkg.backend.Context(0)
