@@ -98,6 +98,8 @@ struct KernelArgs {
     // the wave renders the patch's sixteen tiles itself.  0: every patch gets its sixteen waves.
     uint32_t tail_patches;
     uint32_t tail_first;                     // the tail: patches [tail_first, tail_first + tail_patches) of the order (sky patches behind it keep their sixteen waves: they fill the launch's drain)
+    uint32_t first_round;                    // workgroups resident at once: they do not wait for their tiles' classification; a large launch's sky tail is dealt out behind them
+    uint32_t _pad_first;
     uint32_t order_by_place;                 // launches of more than 4,096 patches: no tile is timed, the order is bottom-up less the sky (which goes to the tail)
     unsigned long long *sort_hint;           // (launch_seq << 32) | patches with something to hit, written by the sorter
     uint32_t launch_seq;
