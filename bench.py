@@ -64,6 +64,13 @@ WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --
 WARMUP_PROBE = 8                # launches timed to find out how many that is
 
 
+def kernel_template_args(name):
+    """rm_render_static<STACK, POW, WAVES, TPW, STAGED, BVH, CULL, EDGES, ORDER, FEEDBACK, HANDON> -> the arguments as strings"""
+    if "<" not in name or ">" not in name:
+        return []
+    return [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")]
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -831,9 +838,10 @@ def rank_main(args):
                                  "written / kernel time (HIP events on the launch stream around the K steps: a step is the "
                                  "render launch and, where tiles are classified, the classification launch in front of it); " + pmc_note},
         }
-        if kernel_name.rstrip(">").endswith("true"):                 # last template argument: FEEDBACK
+        targs = kernel_template_args(kernel_name)                     # ..., EDGES, ORDER, FEEDBACK, HANDON
+        if len(targs) > 9 and targs[9] == "true":
             out["config"]["dispatch"] = FEEDBACK_NOTE
-        elif kernel_name.rstrip(">").endswith("true, false"):        # the one before it: ORDER
+        elif len(targs) > 8 and targs[8] == "true":
             out["config"]["dispatch"] = ORDER_NOTE
         if tiles:
             out["config"]["tiles"] = dict(tiles, note=CLASSIFY_NOTE)
@@ -871,9 +879,10 @@ def rank_main(args):
             if world == 1:
                 t_, v_, n_ = pmc_for(cid, o["kernel_name"], o["best"]["kernel_ms"])
                 other[-1].update(traffic=t_, fp64_valu=v_, pmc=n_, tiles=o["tiles"])
-            if o["kernel_name"].rstrip(">").endswith("true"):         # last template argument: FEEDBACK
+            targs = kernel_template_args(o["kernel_name"])
+            if len(targs) > 9 and targs[9] == "true":
                 other[-1]["dispatch"] = FEEDBACK_NOTE
-            elif o["kernel_name"].rstrip(">").endswith("true, false"):   # the one before it: ORDER
+            elif len(targs) > 8 and targs[8] == "true":
                 other[-1]["dispatch"] = ORDER_NOTE
             o.clear()
 

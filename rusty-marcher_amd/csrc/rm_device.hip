@@ -157,7 +157,8 @@ struct rm_tile_lists {
     // sky tail: the sorter's word in page-locked memory -- (launch seq << 32) | patches with something to hit --, the
     // launches on this stream counted, the first launch of the view being rendered, and that view
     unsigned long long *hint = nullptr;
-    uint32_t seq = 0, view_seq0 = 0;
+    uint32_t seq = 0, view_seq0 = 0, key_seq0 = 0;
+    uint32_t *ov_block = nullptr;     // two blocks of RM_OV_WORDS u32 (count, tally, list), one per launch parity
     double view[7] = {0., 0., 0., 0., 0., 0., 0.};
     // classification at the head of the render launch: the words carry the launch's tag (1..255)
     uint32_t tag = 0, tagged_tiles = 0;
@@ -216,6 +217,7 @@ struct rm_ctx {
     uint32_t patch_order_max = 4096;     // RM_PATCH_ORDER_MAX: launches of up to this many patches take the kernels with the patch order
     uint32_t sky_tail_big_min = 16384;   // RM_SKY_TAIL_BIG_MIN (patches; see RM_SKY_TAIL_BIG_MIN_PATCHES)
     bool sky_tail_big = true;            // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
+    bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_keep = 0;                // RM_SKY_TAIL_KEEP=n: the last n sky patches of the order keep their sixteen waves
     int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
@@ -292,12 +294,12 @@ static constexpr size_t RM_BVH_MIN_SPHERES = 16, RM_BVH_MIN_TRIANGLES = 12;
 // bundles; CULL: bundle culling, EDGES: its edge test for planar primitives, rm_trace.inc;
 // FEEDBACK: longest tiles of the previous frame first).
 #define RM_DECLARE_GROUP(g) \
-    const void *rm_pick_kernel_strict_g##g(bool edges, bool order, int stack, int pow_mode); \
-    const void *rm_pick_kernel_fast_g##g(bool edges, bool order, int stack, int pow_mode);
+    const void *rm_pick_kernel_strict_g##g(bool edges, int order, int stack, int pow_mode); \
+    const void *rm_pick_kernel_fast_g##g(bool edges, int order, int stack, int pow_mode);
 RM_DECLARE_GROUP(0) RM_DECLARE_GROUP(1) RM_DECLARE_GROUP(2) RM_DECLARE_GROUP(3) RM_DECLARE_GROUP(4)
 #undef RM_DECLARE_GROUP
 
-const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool order, bool feedback, int stack, int pow_mode) {
+const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, int order, bool feedback, int stack, int pow_mode) {
     const int group = staged ? (cull ? 1 : 0) : !bvh ? 2 : feedback ? 4 : 3;
     if (staged && (bvh || feedback)) return nullptr;         // no such kernel: small scenes have no hierarchy
     if (!staged && !cull) return nullptr;                    // scenes in global memory always cull
@@ -368,6 +370,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG")) ctx->sky_tail_big = env[0] != '0';
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG_MIN")) ctx->sky_tail_big_min = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_PLACE")) ctx->sky_tail_place = env[0] == 'e' && env[1] == 'v' ? 1 : env[0] == 'e' ? 2 : 0;
+    if (const char *env = std::getenv("RM_SKY_TAIL_MOTION")) ctx->sky_tail_motion = env[0] != '0';
     if (const char *env = std::getenv("RM_SKY_TAIL_KEEP")) ctx->sky_tail_keep = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
@@ -407,6 +410,7 @@ void rm_destroy(rm_ctx *ctx) {
             if (t.block) (void)hipFree(t.block);
             if (t.order_block) (void)hipFree(t.order_block);
             if (t.hint) (void)hipHostFree(t.hint);
+            if (t.ov_block) (void)hipFree(t.ov_block);
         }
         if (ctx->d_scene) (void)hipFree(ctx->d_scene);
         if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -883,6 +887,7 @@ static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 4608, RM_CLASSIFY_STREAMS = 8;
 // Launches of this many patches and more take the kernels with the patch order for the sky tail alone (order_by_place):
 // measured 8K 987 -> 960 us; at 4K (8,100 patches) the sorting workgroup and the order's indirection cost what the tail saves
 // (245.3 against 243.8 us).
+static constexpr uint32_t RM_TAIL_ROLES = 32768;       // (patches of a guessed tail: 8K has 32,400)
 static constexpr uint32_t RM_SKY_TAIL_BIG_MIN_PATCHES = 16384;   // (rm_ctx::sky_tail_big_min)
 // What a lane of the classification spends on its share of a patch's primitives, in vector instructions: ~22
 // per bounding sphere, ~110 more for the edge and plane tests of a planar primitive.  Beyond this the launch
@@ -901,6 +906,7 @@ static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tile
             if (ctx->tile_lists[old].block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].block));   // (waits for the device)
             if (ctx->tile_lists[old].order_block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].order_block));
             if (ctx->tile_lists[old].hint) RM_HIP(ctx, hipHostFree(ctx->tile_lists[old].hint));
+            if (ctx->tile_lists[old].ov_block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].ov_block));
             ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)old);
         }
         ctx->tile_lists.emplace_back();
@@ -967,7 +973,7 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE &&
                (tiles / 16u <= ctx->patch_order_max || (ctx->sky_tail && ctx->sky_tail_big && n_prims <= 56u && tiles / 16u >= ctx->sky_tail_big_min)) &&
                (ctx->patch_order_mode == 1 || tiles >= RM_CLASSIFY_MIN_TILES);
-    k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order, k->feedback, st, pw);
+    k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order ? 1 : 0, k->feedback, st, pw);
     if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
     return RM_OK;
 }
@@ -1156,8 +1162,13 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             if (!tl->hint) {
                 RM_HIP(ctx, hipHostMalloc((void **)&tl->hint, sizeof(unsigned long long), hipHostMallocDefault));
                 *tl->hint = 0ull;
+                RM_HIP(ctx, hipMalloc((void **)&tl->ov_block, (2u * RM_OV_WORDS + RM_TAIL_ROLES) * sizeof(uint32_t)));
+                RM_HIP(ctx, hipMemsetAsync(tl->ov_block, 0, (2u * RM_OV_WORDS + RM_TAIL_ROLES) * sizeof(uint32_t), stream));
             }
+            if (*(volatile unsigned long long *)tl->hint == ~0ull)
+                return ctx_fail(ctx, RM_ERR_HIP, "render: the sky tail's hand-over timed out in an earlier launch on this stream (that frame is void)");
             const uint32_t seq = ++tl->seq;
+            if (f == 0u) tl->key_seq0 = seq;
             const double view[7] = {ctx->camera.x, ctx->camera.y, ctx->camera.z, p->half_fov, p->height, p->width, p->ratio};
             if (f == 0u || std::memcmp(tl->view, view, sizeof view) != 0) {
                 std::memcpy(tl->view, view, sizeof view);
@@ -1165,17 +1176,28 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             }
             a.sort_hint = tl->hint;
             a.launch_seq = seq;
+            a.ov_zero = tl->ov_block + ((seq + 1u) & 1u) * RM_OV_WORDS;   // (the next launch's block: cleared by this launch's sorting workgroup)
             a.order_by_place = n_patches > ctx->patch_order_max ? 1u : 0u;
             if (ctx->sky_tail && a.cls_blocks && a.patch_order) {
                 uint32_t tail = 0, keep = 0;
+                bool guess = false;
                 if (ctx->sky_tail_force >= 0) {                                 // (test hook: a hint that is wrong)
                     tail = std::min((uint32_t)ctx->sky_tail_force, n_patches);
-                } else if (seq >= tl->view_seq0 + 2u) {
+                    guess = true;
+                } else if (seq >= tl->key_seq0 + 2u) {
                     // (the order in use was sorted from the frame two launches back, the hint from the frame before its
-                    // sorter's launch: both must be frames of this view)
+                    // sorter's launch: frames of this view -> the hint is exact; of this scene and frame geometry, the view
+                    // has moved since -> it is a guess, and what it gets wrong is handed on to waves at the grid's end)
                     const unsigned long long h = *(volatile unsigned long long *)tl->hint;
                     const uint32_t h_seq = (uint32_t)(h >> 32), n_lit = (uint32_t)h;
-                    if (h_seq >= tl->view_seq0 + 1u && h_seq < seq && n_lit <= n_patches) tail = n_patches - n_lit;
+                    const bool exact = seq >= tl->view_seq0 + 2u && h_seq >= tl->view_seq0 + 1u;
+                    guess = !exact;
+                    if ((exact || ctx->sky_tail_motion) && h_seq >= tl->key_seq0 + 1u && h_seq < seq && n_lit <= n_patches) tail = n_patches - n_lit;
+                    // (a guess only where the sky is most of the frame: there the tail is a third of the launch -- Cornell box,
+                    // camera on the move, 40.0 -> 35.5 us -- and a camera that jumps hands on a few dozen patches; where it is half
+                    // of the frame the tail buys 1 % and a jump that turns more patches than the hand-over has room for leaves them
+                    // to single waves: demo scene 86 -> 208 us a frame with a jump every few frames)
+                    if (guess && ctx->sky_tail_force < 0 && 5u * (uint64_t)tail < 3u * (uint64_t)n_patches) tail = 0u;
                     // (the last sky patches keep their sixteen waves: short waves that fill the launch's drain)
                     tail -= std::min(tail, (uint32_t)ctx->sky_tail_keep);
                     if (tail < 8u) tail = 0u;
@@ -1184,6 +1206,15 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 a.tail_patches = tail;
                 a.tail_first = n_patches - tail - (tail ? keep : 0u);
                 grid.x -= 15u * tail;
+                if (tail && guess && tail <= RM_TAIL_ROLES) {
+                    a.tail_role = tl->ov_block + 2u * RM_OV_WORDS;
+                    a.ov_cap = std::min(tail, std::min(RM_OV_PATCHES, std::max(128u, n_patches / 8u)));
+                    a.ov_ctl = tl->ov_block + (seq & 1u) * RM_OV_WORDS;
+                    grid.x += 16u * a.ov_cap;
+                    // (the kernel with the hand-over: a kernel of its own -- its code costs the waves that render 2-3 %)
+                    fn = rm_pick_kernel(k.fast, k.staged, k.bvh, k.cull, k.edges, 2, false, k.stack, k.pow_mode);
+                    if (!fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel with the hand-over for this scene / depth combination");
+                }
                 // (dealt out evenly among the tile waves behind the launch's first round: rm_render_kernel.inc)
                 const uint64_t head_ids = a.n_tiles - 16u * tail, behind = head_ids - std::min<uint64_t>(a.first_round, head_ids);
                 a.tail_q = (tail && behind) ? (uint32_t)((((uint64_t)tail << 32) + behind + tail - 1u) / (behind + tail)) : 0u;
@@ -1205,6 +1236,12 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
     ctx->last_launch_grid = grid.x;
     ctx->last_launch_tail = a.tail_patches;
+    if (a.ov_cap && std::getenv("RM_DEBUG_TAIL")) {                     // (diagnostic: waits for the launch)
+        uint32_t c[2] = {0u, 0u};
+        RM_HIP(ctx, hipStreamSynchronize(stream));
+        RM_HIP(ctx, hipMemcpy(c, a.ov_ctl, sizeof c, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[rm_tail] launch %u: tail %u patches, room for %u to hand on, %u handed on, %u decided\n", a.launch_seq, a.tail_patches, a.ov_cap, c[0], c[1]);
+    }
     if (fb) fb->cur = (fb->cur + 1) % 3;
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     RM_HIP(ctx, hipStreamSynchronize(stream));
@@ -1322,7 +1359,8 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     st = choose_kernel(ctx, params, band.count() * (params->frame_width / RM_PATCH_SIZE) * 16u, &k);
     if (st != RM_OK) return st;
     // the name rocprofv3's kernel trace shows (template arguments in declaration order)
-    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+    // (the last one, HANDON: the kernel of a launch whose sky tail is sized by a guess -- not what a settled render loop launches)
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s, false>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
                   k.cull ? "true" : "false", k.edges ? "true" : "false", k.order ? "true" : "false", k.feedback ? "true" : "false");
     return RM_OK;

@@ -9,6 +9,9 @@
 #include "rm_internal.h"
 
 #define RM_BVH_NODE_WORDS 16u
+// patches a tail whose hint is a guess can hand on to waves at the grid's end; the block: count, tally, list
+#define RM_OV_PATCHES 512u
+#define RM_OV_WORDS (2u + RM_OV_PATCHES)
 
 // waves per SIMD the integer-power kernels are compiled for (register budget 512 / this)
 #ifndef RM_MIN_WAVES
@@ -98,8 +101,15 @@ struct KernelArgs {
     // the wave renders the patch's sixteen tiles itself.  0: every patch gets its sixteen waves.
     uint32_t tail_patches;
     uint32_t tail_first;                     // the tail: patches [tail_first, tail_first + tail_patches) of the order (sky patches behind it keep their sixteen waves: they fill the launch's drain)
+    // ... and where the view has MOVED since the frames the hint came from (it is then a guess): the workgroup that classifies a
+    // patch of the tail and finds something to hit in it hands the patch to sixteen waves at the very end of the grid (ov_cap
+    // patches of them; the list is ov_ctl[2..], its count ov_ctl[0]; ov_ctl[1] counts the classifying workgroups that are
+    // done), or back to the tail's own wave when that list is full.  ov_zero: the next launch's block, cleared by this
+    // launch's sorting workgroup.
+    uint32_t *ov_ctl, *ov_zero;              // RM_OV_WORDS u32 each
+    uint32_t *tail_role;                     // per patch of the tail: (launch_seq << 2) | 1 handed on / 2 the tail's wave renders it
+    uint32_t ov_cap;
     uint32_t first_round;                    // workgroups resident at once: they do not wait for their tiles' classification; a large launch's sky tail is dealt out behind them
-    uint32_t _pad_first;
     uint32_t order_by_place;                 // launches of more than 4,096 patches: no tile is timed, the order is bottom-up less the sky (which goes to the tail)
     unsigned long long *sort_hint;           // (launch_seq << 32) | patches with something to hit, written by the sorter
     uint32_t launch_seq;
@@ -144,6 +154,6 @@ struct StackEntry {
 
 // The kernel of a launch (rm_kernels.hip, compiled once per numeric flavour and kernel group):
 // stack 4 / 8 / 16 / 32, pow_mode POW_GENERIC / POW_INTEGER.  NULL: no such instantiation.
-const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, bool order, bool feedback, int stack, int pow_mode);
+const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, int order, bool feedback, int stack, int pow_mode);   // order: 0 off, 1 the patch order, 2 ... with the hand-over of a guessed tail
 
 #endif

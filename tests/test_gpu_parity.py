@@ -145,7 +145,8 @@ def test_config_c5_synthetic_bands(pkg, O, ctx):
     ctx.upload(workloads.product_scene(pkg, "synthetic256").flatten())
     p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
     p.flags = _FLAGS["value"]
-    assert ctx.kernel_name(p).rstrip(">").endswith("true"), "C5 is expected to run the kernel with the feedback"
+    targs = [x.strip() for x in ctx.kernel_name(p).split("<", 1)[1].rstrip(">").split(",")]   # ..., ORDER, FEEDBACK, HANDON
+    assert targs[9] == "true", "C5 is expected to run the kernel with the feedback"
     so = workloads.oracle_scene(O, "synthetic256")
     ref = np.zeros((h, w, 3), dtype=np.float64)
     rows = [0, 23, 47, 64, 77, 96, 111, 127]
@@ -802,7 +803,10 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     plain = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL", "1")
     monkeypatch.setenv("RM_SKY_TAIL_KEEP", "0")                     # (frames of a few hundred patches: every sky patch to the tail)
+    monkeypatch.setenv("RM_SKY_TAIL_MOTION", "0")                   # (no guesses: a hint only from frames of the view being rendered)
     tail = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_SKY_TAIL_MOTION")
+    moving = pkg.backend.Context(0)                                 # (the default: a moved view takes the hint as a guess where the sky is most of the frame: the Cornell box)
     monkeypatch.setenv("RM_SKY_TAIL_KEEP", "16")                    # (the last sixteen sky patches keep their sixteen waves,
     monkeypatch.setenv("RM_SKY_TAIL_PLACE", "even")                 # the tail's waves dealt out among the tile waves, not behind them)
     tail_keep = pkg.backend.Context(0)
@@ -822,17 +826,20 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     cornell = workloads.product_scene(pkg, "cornell")
     seq = [(demo, (0., 0., 0.), 640, 352, 5, None)] * 6 + [(demo, (0., 5., 0.), 640, 352, 5, None)] * 5 + \
           [(demo, (0., 5. + k, -2. * k), 640, 352, 5, None) for k in range(4)] + \
+          [(demo, (0.5 * k, 0.3 * k, -0.4 * k), 640, 352, 5, None) for k in range(8)] + \
           [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 5 + [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 6 + \
+          [(cornell, (3. * k, 2. * k, -5. * (k % 3)), 640, 352, 3, None) for k in range(1, 9)] + \
           [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 5
-    armed = {"tail": 0, "tail_keep": 0, "by_place": 0, "wrong_some": 0, "wrong_all": 0}
+    armed = {"tail": 0, "moving": 0, "tail_keep": 0, "by_place": 0, "wrong_some": 0, "wrong_all": 0}
+    armed_on_a_new_view = 0
     try:
         for k, (scene, cam, w, h, depth, band) in enumerate(seq):
             scene.camera = pkg.Vec3f(*cam)
             p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
             p.flags = _FLAGS["value"]
             outs = []
-            for name, c in (("plain", plain), ("tail", tail), ("tail_keep", tail_keep), ("by_place", by_place), ("wrong_some", wrong_some),
-                            ("wrong_all", wrong_all)):
+            for name, c in (("plain", plain), ("tail", tail), ("moving", moving), ("tail_keep", tail_keep), ("by_place", by_place),
+                            ("wrong_some", wrong_some), ("wrong_all", wrong_all)):
                 if os.environ.get("RM_TEST_TRACE"):
                     print("frame", k, name, cam, w, h, depth, band, flush=True)
                 c.upload(scene.flatten())
@@ -847,20 +854,25 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
                     assert n_tail == 0
                 else:
                     armed[name] += n_tail > 0
-                # a hint is taken only from frames of the view being rendered: none in the first two frames of a view
-                if name in ("tail", "tail_keep", "by_place") and (k < 2 or seq[k][:4] != seq[k - 1][:4] or seq[k][:4] != seq[k - 2][:4]
-                                                                  or seq[k][5] != seq[k - 1][5] or seq[k][5] != seq[k - 2][5]):
-                    assert n_tail == 0, "frame %d (%s): %d patches in the tail of a view that is %s" % (k, name, n_tail, "new")
-            for j in (1, 2, 3, 4, 5):
+                # without guesses a hint is taken only from frames of the view being rendered: none in the first two frames of
+                # a view; with them (the default) a view that has moved keeps the tail -- what it gets wrong is handed on
+                new_view = (k < 2 or seq[k][:4] != seq[k - 1][:4] or seq[k][:4] != seq[k - 2][:4]
+                            or seq[k][5] != seq[k - 1][5] or seq[k][5] != seq[k - 2][5])
+                if name == "tail" and new_view:
+                    assert n_tail == 0, "frame %d (%s): %d patches in the tail of a view that is new" % (k, name, n_tail)
+                if name == "moving" and new_view:
+                    armed_on_a_new_view += n_tail > 0
+            for j in (1, 2, 3, 4, 5, 6):
                 assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the sky tail on (%d)" % (k, j)
                 assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
             if band is None:
                 assert not (outs[1][0][:h // 32 * 32] == -1.).any()
         # the tail armed itself where a view was held, and the wrong hints were in force
         assert armed["tail"] >= 8 and armed["tail_keep"] >= 8 and armed["by_place"] >= 8, armed
+        assert armed["moving"] > armed["tail"] and armed_on_a_new_view >= 3, (armed, armed_on_a_new_view)
         assert armed["wrong_some"] >= 15 and armed["wrong_all"] >= 15, armed
     finally:
-        for c in (plain, tail, tail_keep, by_place, wrong_some, wrong_all):
+        for c in (plain, tail, moving, tail_keep, by_place, wrong_some, wrong_all):
             c.close()
 
 
