@@ -55,10 +55,10 @@ CLASSIFY_NOTE = ("a launch of 16 lanes per 32x32 patch in front of the render la
                  "that stores the primary-miss value and leaves; every other pixel is traced in full; kernel_ms and ms_per_step "
                  "include that launch")
 ORDER_NOTE = ("patch order: the 32x32 patches whose longest tile took longest in the previous frames on the stream are dispatched "
-              "first (RM_PATCH_ORDER=0 switches it off); sky tail: while the view is the one those frames had, patches their "
-              "classification found nothing to hit in get one wave instead of sixteen -- it looks at THIS launch's classification "
-              "of its patch, stores the primary-miss value where that still says sky and renders the patch itself where it does "
-              "not (RM_SKY_TAIL=0 switches it off); only the order and the geometry of the launch are carried from frame to "
+              "first (RM_PATCH_ORDER=0 switches it off); sky tail: while the view is the one those frames had (this bench: always), "
+              "patches their classification found nothing to hit in get one wave instead of sixteen -- it looks at THIS launch's "
+              "classification of its patch, stores the primary-miss value where that still says sky and renders the patch itself "
+              "where it does not (RM_SKY_TAIL=0 switches it off); only the order and the geometry of the launch are carried from frame to "
               "frame: every frame classifies every patch and every pixel with something to hit is traced in full")
 WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
 WARMUP_PROBE = 8                # launches timed to find out how many that is
