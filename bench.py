@@ -60,6 +60,9 @@ ORDER_NOTE = ("patch order: the 32x32 patches whose longest tile took longest in
               "classification of its patch, stores the primary-miss value where that still says sky and renders the patch itself "
               "where it does not (RM_SKY_TAIL=0 switches it off); only the order and the geometry of the launch are carried from frame to "
               "frame: every frame classifies every patch and every pixel with something to hit is traced in full")
+MOTION_NOTE = ("the reference renders only after a camera move or a scene change (main.rs:74-78, :119-170): rm_camera_update before "
+               "EVERY launch, the camera one button press (+-5 on one axis) from where it was (workloads.camera_walk), the scene "
+               "resident; same stream, same outputs, same HIP-event bracket around the K steps as the metric")
 WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
 WARMUP_PROBE = 8                # launches timed to find out how many that is
 
@@ -94,6 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sizes", action="store_true",
                     help="skip the extras reported beside the metric (other configs, rm_render into host memory)")
+    ap.add_argument("--no-motion", action="store_true", help="skip the camera_on_the_move leg (the camera moving before every launch)")
     ap.add_argument("--check", action="store_true", help="also compare the frame with the oracle")
     ap.add_argument("--deadline", type=float, default=900.,
                     help="self-spawned runs (--gpus N > 1 without a launcher): seconds after which the rank processes are killed")
@@ -452,7 +456,7 @@ def rank_main(args):
             return False
         return True
 
-    def run_workload(cfg_id, steps, warmup, extras=False):
+    def run_workload(cfg_id, steps, warmup, extras=False, motion=False):
         """Warm-up, then `steps` frames of one workload between fences -- at N > 1 once per
         exchange path; returns the timings and what rank 0 holds afterwards."""
         cfg = workloads.CONFIGS[cfg_id]
@@ -511,6 +515,14 @@ def rank_main(args):
                 raise pkg.BackendError(st, L.rm_last_error(ctx.ptr).decode())
 
         def step_single():
+            check(L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[0], frame8_ptr, stream_ptr))
+
+        # the call pattern the reference has: the camera moves, then render() (main.rs:74-78)
+        walk = [pkg._lib.vec3(pkg.Vec3f(*c)) for c in workloads.camera_walk()]
+
+        def step_walk():
+            check(L.rm_camera_update(ctx.ptr, walk[counter[0] % len(walk)]))
+            counter[0] += 1
             check(L.rm_render_device_u8(ctx.ptr, p_ref, frame_ptrs[0], frame8_ptr, stream_ptr))
 
         def step_direct():
@@ -675,6 +687,36 @@ def rank_main(args):
 
         best = paths[chosen]
         tiles = None
+        moving = None
+        if motion and not use_dist:
+            # (after the metric's own run: the standing view's history is on the stream, as in a host that has just stopped)
+            mv = timed(step_walk, False)
+            moving = {"value": mv["mpx"], "unit": "Mpixels/s", "steps": steps, "ms_per_step": mv["ms_per_step"],
+                      "kernel_ms": mv["kernel_ms"], "camera": "every frame one press from the last", "what": MOTION_NOTE}
+            # a view held for four frames: its first frame and its fourth, each launch in an event bracket of its own
+            firsts, fourths = [], []
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+            for v in range(12 + min(max(steps, 8), 40)):
+                check(L.rm_camera_update(ctx.ptr, walk[(7 * v) % len(walk)]))
+                for f in range(4):
+                    e = evs[0] if f == 0 else evs[1] if f == 3 else None
+                    if e:
+                        e[0].record(stream)
+                    step_single()
+                    if e:
+                        e[1].record(stream)
+                fence()
+                if v >= 12:
+                    firsts.append(evs[0][0].elapsed_time(evs[0][1]))
+                    fourths.append(evs[1][0].elapsed_time(evs[1][1]))
+            moving["first_frame_of_a_view"] = {"kernel_ms_median": float(np.median(firsts)), "fourth_frame_of_the_view_kernel_ms_median": float(np.median(fourths)),
+                                               "views": len(firsts), "what": "a view held for four frames, every view a jump to another point of the walk; "
+                                                                             "each launch timed by an event pair of its own (which costs a few us)"}
+            check(L.rm_camera_update(ctx.ptr, pkg._lib.vec3(scene.camera)))
+            counter[0] = 0
+            for _ in range(3):
+                step_single()
+            fence()
         if not use_dist:
             n_t, n_lit = ctx.tile_stats(stream.cuda_stream)
             tiles = {"tiles": n_t, "with_something_to_hit": n_lit,
@@ -785,12 +827,12 @@ def rank_main(args):
             if u8 is not None:
                 checks["display_bytes_differing_from_oracle"] = int((u8.cpu().numpy().reshape(-1) != O.to_vec(ref.copy())).sum())
         res = dict(cfg=cfg, paths=paths, chosen=chosen, kernel_name=kernel_name, n_owned=n_owned, c_rows=c_rows, cyclic=cyclic,
-                   host=host, piped=piped, checks=checks, px_launch=px_launch, best=best, tiles=tiles)
+                   host=host, piped=piped, checks=checks, px_launch=px_launch, best=best, tiles=tiles, moving=moving)
         ctx.close()
         torch.cuda.empty_cache()
         return res
 
-    def result(cfg, paths, chosen, note, kernel_name, n_owned, c_rows, cyclic, host, piped, checks, other, tiles=None):
+    def result(cfg, paths, chosen, note, kernel_name, n_owned, c_rows, cyclic, host, piped, checks, other, tiles=None, moving=None):
         """The JSON line."""
         w, h, depth = cfg["width"], cfg["height"], cfg["max_depth"]
         best = paths[chosen]
@@ -851,6 +893,8 @@ def rank_main(args):
             out.update(checks)
         if host:
             out["end_to_end_host"] = host
+        if moving:
+            out["camera_on_the_move"] = moving
         if piped:
             out["four_frames_in_flight"] = piped
         if other:
@@ -861,7 +905,7 @@ def rank_main(args):
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
 
-    r = run_workload(args.config, args.steps, args.warmup, extras=not args.no_sizes)
+    r = run_workload(args.config, args.steps, args.warmup, extras=not args.no_sizes, motion=not args.no_motion)
     # north star: "Mpixels/sec on synthetic 1080p/4K/8K frames", and the other GPU configs of
     # BASELINE.json (cornell C3, synthetic C5): a short run each (same sharding and collective),
     # reported beside the metric with their own kernel and roofline fraction
@@ -869,7 +913,7 @@ def rank_main(args):
     if args.config == "C2" and not args.no_sizes:
         for cid in ("C2_4K", "C4", "C3", "C5"):
             k = max(5, min(args.steps, 20 if cid != "C3" else 100))
-            o = run_workload(cid, k, 3)
+            o = run_workload(cid, k, 3, motion=(cid == "C3"))
             ach = o["px_launch"] * BYTES_PER_PIXEL / (o["best"]["kernel_ms"] * 1e-3) / 1e9
             other.append({"workload": "%s: %s scene %dx%d, depth cap %d" % (cid, o["cfg"]["scene"], o["cfg"]["width"], o["cfg"]["height"], o["cfg"]["max_depth"]),
                           "value": o["best"]["mpx"], "unit": "Mpixels/s", "steps": k, "ms_per_step": o["best"]["ms_per_step"],
@@ -879,6 +923,8 @@ def rank_main(args):
             if world == 1:
                 t_, v_, n_ = pmc_for(cid, o["kernel_name"], o["best"]["kernel_ms"])
                 other[-1].update(traffic=t_, fp64_valu=v_, pmc=n_, tiles=o["tiles"])
+                if o["moving"]:
+                    other[-1]["camera_on_the_move"] = o["moving"]
             targs = kernel_template_args(o["kernel_name"])
             if len(targs) > 9 and targs[9] == "true":
                 other[-1]["dispatch"] = FEEDBACK_NOTE
@@ -888,7 +934,7 @@ def rank_main(args):
 
     if rank == 0:
         out = result(r["cfg"], r["paths"], r["chosen"], None, r["kernel_name"], r["n_owned"], r["c_rows"], r["cyclic"],
-                     r["host"], r["piped"], r["checks"], other, r["tiles"])
+                     r["host"], r["piped"], r["checks"], other, r["tiles"], r["moving"])
         if world == 1 and not args.no_cpu_baseline:
             O = G.load_oracle()
             out["cpu_baseline"] = cpu_baseline(O, workloads, r["cfg"])

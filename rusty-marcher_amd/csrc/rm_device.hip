@@ -148,17 +148,24 @@ struct rm_tile_lists {
     uint32_t cap = 0;                 // tiles the masks have room for
     void *block = nullptr;            // mask[cap] u64
     uint64_t used = 0;
-    // patch order (launches of up to 4,096 patches): cost[2][cap16] | order[2][cap16] u32, frames since the last reset
+    // Dispatch order from the launch's own classification (KernelArgs::ord_*), one block per stream:
+    //   sig[2][cap] u64 | cost[2][cap] u32 | ctab[2][64] u32 | ctl[2][32] u32 | list[16][cap] u32      (cap: patches)
+    // the pairs alternate from launch to launch (a launch reads what its predecessor on the stream wrote)
     void *order_block = nullptr;
     uint32_t order_cap = 0, order_frames = 0;
     uint64_t order_key[3] = {0, 0, 0};
-    uint32_t *cost(uint32_t j) const { return static_cast<uint32_t *>(order_block) + (size_t)j * order_cap; }
-    uint32_t *order(uint32_t j) const { return static_cast<uint32_t *>(order_block) + (size_t)(2u + j) * order_cap; }
-    // sky tail: the sorter's word in page-locked memory -- (launch seq << 32) | patches with something to hit --, the
-    // launches on this stream counted, the first launch of the view being rendered, and that view
+    unsigned long long *sig(uint32_t j) const { return static_cast<unsigned long long *>(order_block) + (size_t)j * order_cap; }
+    uint32_t *words() const { return reinterpret_cast<uint32_t *>(sig(2)); }
+    uint32_t *cost(uint32_t j) const { return words() + (size_t)j * order_cap; }
+    uint32_t *ctab(uint32_t j) const { return words() + 2u * (size_t)order_cap + j * RM_CTAB_WORDS; }
+    uint32_t *ctl(uint32_t j) const { return words() + 2u * (size_t)order_cap + 2u * RM_CTAB_WORDS + j * RM_ORD_CTL_WORDS; }
+    uint32_t *list() const { return words() + 2u * (size_t)order_cap + 2u * RM_CTAB_WORDS + 2u * RM_ORD_CTL_WORDS; }
+    static size_t order_bytes(uint32_t cap) { return (size_t)cap * 16u + ((size_t)cap * (2u + RM_ORD_BUCKETS) + 2u * RM_CTAB_WORDS + 2u * RM_ORD_CTL_WORDS) * 4u; }
+    // sky tail: the last classifying workgroup's word in page-locked memory -- (launch seq << 32) | ordered patches with something
+    // to hit --, behind it the word a wave writes when it gives up a wait that cannot fail; the launches on this stream counted, the
+    // first launch of the view being rendered, the first of this geometry and scene, and that view
     unsigned long long *hint = nullptr;
-    uint32_t seq = 0, view_seq0 = 0, key_seq0 = 0;
-    uint32_t *ov_block = nullptr;     // two blocks of RM_OV_WORDS u32 (count, tally, list), one per launch parity
+    uint32_t seq = 0, view_seq0 = 0, key_seq0 = 0, ord_tag = 0;
     double view[7] = {0., 0., 0., 0., 0., 0., 0.};
     // classification at the head of the render launch: the words carry the launch's tag (1..255)
     uint32_t tag = 0, tagged_tiles = 0;
@@ -219,7 +226,11 @@ struct rm_ctx {
     bool sky_tail_big = true;            // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
-    int sky_tail_keep = 0;                // RM_SKY_TAIL_KEEP=n: the last n sky patches of the order keep their sixteen waves
+    int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    int first_round = -1;                // RM_FIRST_ROUND=n: the waves that neither wait for their tiles' classification nor take a place in the order (unset: what is resident at once)
+    int order_keys = -1;                 // RM_ORDER_KEYS=0 by place only, 1 the previous frame's times by place only, 2 cost by content only (A/B knob; unset: times while the view stands, content once it has moved)
+    uint32_t ord_tag_wrap = 0;           // RM_ORD_TAG_WRAP=n (test hook): the order's tags start afresh after n launches instead of 4,095
+    bool test_stall_order = false;       // RM_TEST_STALL_ORDER=1 (test hook): the waves wait for one classifying workgroup more than there is
     int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
     int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
     std::vector<rm_tile_lists> tile_lists;
@@ -371,7 +382,11 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG_MIN")) ctx->sky_tail_big_min = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_PLACE")) ctx->sky_tail_place = env[0] == 'e' && env[1] == 'v' ? 1 : env[0] == 'e' ? 2 : 0;
     if (const char *env = std::getenv("RM_SKY_TAIL_MOTION")) ctx->sky_tail_motion = env[0] != '0';
-    if (const char *env = std::getenv("RM_SKY_TAIL_KEEP")) ctx->sky_tail_keep = std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_SKY_TAIL_CAP")) ctx->sky_tail_cap = std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_ORDER_KEYS")) ctx->order_keys = std::atoi(env);
+    if (const char *env = std::getenv("RM_FIRST_ROUND")) ctx->first_round = std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
+    if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
@@ -410,7 +425,6 @@ void rm_destroy(rm_ctx *ctx) {
             if (t.block) (void)hipFree(t.block);
             if (t.order_block) (void)hipFree(t.order_block);
             if (t.hint) (void)hipHostFree(t.hint);
-            if (t.ov_block) (void)hipFree(t.ov_block);
         }
         if (ctx->d_scene) (void)hipFree(ctx->d_scene);
         if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -887,7 +901,6 @@ static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 4608, RM_CLASSIFY_STREAMS = 8;
 // Launches of this many patches and more take the kernels with the patch order for the sky tail alone (order_by_place):
 // measured 8K 987 -> 960 us; at 4K (8,100 patches) the sorting workgroup and the order's indirection cost what the tail saves
 // (245.3 against 243.8 us).
-static constexpr uint32_t RM_TAIL_ROLES = 32768;       // (patches of a guessed tail: 8K has 32,400)
 static constexpr uint32_t RM_SKY_TAIL_BIG_MIN_PATCHES = 16384;   // (rm_ctx::sky_tail_big_min)
 // What a lane of the classification spends on its share of a patch's primitives, in vector instructions: ~22
 // per bounding sphere, ~110 more for the edge and plane tests of a planar primitive.  Beyond this the launch
@@ -906,7 +919,6 @@ static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tile
             if (ctx->tile_lists[old].block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].block));   // (waits for the device)
             if (ctx->tile_lists[old].order_block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].order_block));
             if (ctx->tile_lists[old].hint) RM_HIP(ctx, hipHostFree(ctx->tile_lists[old].hint));
-            if (ctx->tile_lists[old].ov_block) RM_HIP(ctx, hipFree(ctx->tile_lists[old].ov_block));
             ctx->tile_lists.erase(ctx->tile_lists.begin() + (long)old);
         }
         ctx->tile_lists.emplace_back();
@@ -921,6 +933,22 @@ static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tile
         RM_HIP(ctx, hipMalloc(&t->block, (size_t)n_tiles * sizeof(unsigned long long)));
     }
     *out = t;
+    return RM_OK;
+}
+
+// A wave that gives up a wait that cannot fail (the dispatch order of its own launch, 10 ms) says so in page-locked memory
+// and renders nothing: that frame is void.  Reported once, by the first call that has waited for the device since -- the
+// synchronous render calls and rm_frame_wait report the void frame itself -- or by the next launch on the stream.
+static rm_status void_frame_check(rm_ctx *ctx, const char *who) {
+    for (rm_tile_lists &t : ctx->tile_lists)
+        if (t.hint) {
+            const unsigned long long e = *(volatile unsigned long long *)(t.hint + 1);
+            if (e) {
+                *(volatile unsigned long long *)(t.hint + 1) = 0ull;
+                return ctx_fail(ctx, RM_ERR_HIP, std::string(who) + ": launch " + std::to_string((uint32_t)(e >> 32)) +
+                                                     " of its stream gave up waiting for its own classification (that frame is void)");
+            }
+        }
     return RM_OK;
 }
 
@@ -1044,6 +1072,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     // the launch's first round -- the waves resident at once -- does not wait for its tiles' classification (Cornell, whose
     // edge-test kernel holds three waves to a SIMD: 31.5 -> 30.8 us with 3,072 instead of 4,096)
     a.first_round = (uint32_t)ctx->prop.multiProcessorCount * 4u * (k.edges ? RM_EDGES_WAVES : RM_MIN_WAVES);
+    if (ctx->first_round >= 0) a.first_round = (uint32_t)ctx->first_round;     // (RM_FIRST_ROUND: A/B knob, and how the tests reach the order in frames of a few thousand tiles)
     const rm_launch_mode m = k.mode;
     const size_t lds = k.lds_bytes;
     const dim3 block(m.waves * 64);
@@ -1117,56 +1146,52 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             a.mask_exact = n_prims_all <= 64u ? 1u : 0u;
         }
     }
-    // Patch order (launches of up to 4,096 patches, without the tile-level feedback): the waves add their tiles' times to
-    // their patches' counters; the workgroup behind the classifying ones sorts the PREVIOUS launch's counters into the
-    // order the NEXT launch on this stream dispatches by: the patches that took longest first.  A 1080p launch is four
-    // tiles deep per wave slot and used to end with the top of the glass sphere -- 30 us tiles dispatched at 40 us of 78.
-    // Only the order of dispatch is carried over: every tile of every frame is rendered in full by the same code.
+    // Dispatch order from the launch's own classification, and the sky tail (KernelArgs::ord_*; rm_classify.inc place_patch /
+    // cls_finish, rm_render_kernel.inc order_entry / sky_tail_patch).  The reference renders only after the camera has moved
+    // (main.rs:74-78): an order by place from earlier frames is stale exactly then (r3: demo 1080p 68.5 us standing, 78.7 with a
+    // press before every frame).  The classifying workgroups at the launch's head put every patch behind the first round into
+    // one of sixteen buckets -- by its longest tile's time in the previous frame while the view stands still, by the cost of what
+    // it can reach (learned per primitive from earlier frames: it moves with the picture) once it has moved, the sky last.
+    // Only the order of dispatch and the launch's geometry depend on any of it: every tile of every frame is rendered in full by
+    // the same code, exactly once.
     {
         const uint32_t n_patches = a.n_tiles / 16u;
-        const bool reorder = k.order && per_wg == 1u;
-        if (reorder) {
+        a.n_static = std::min(a.first_round & ~15u, a.n_tiles);
+        const uint32_t n_dyn = n_patches - a.n_static / 16u;
+        const bool ordered = k.order && per_wg == 1u && a.cls_blocks != 0u && n_dyn > 0u && n_patches < (1u << RM_ORD_PATCH_BITS);
+        if (ordered) {
             rm_tile_lists *tl = nullptr;
             rm_status ost = tile_lists_for(ctx, stream, a.n_tiles, &tl);
             if (ost != RM_OK) return ost;
             const uint64_t key[3] = {(uint64_t)a.n_tiles | ((uint64_t)p->frame_width << 32), (uint64_t)row_begin | ((uint64_t)band.stride << 32),
-                                     ctx->scene_epoch};
+                                     ctx->scene_epoch ^ ((uint64_t)a.n_static << 40)};
             if (!tl->order_block || tl->order_cap < n_patches) {
                 if (tl->order_block) RM_HIP(ctx, hipFree(tl->order_block));     // (waits for the device)
                 tl->order_block = nullptr;
                 tl->order_cap = n_patches;
-                RM_HIP(ctx, hipMalloc(&tl->order_block, 4u * (size_t)n_patches * sizeof(uint32_t)));
-                tl->order_frames = 0;
+                RM_HIP(ctx, hipMalloc(&tl->order_block, rm_tile_lists::order_bytes(n_patches)));
                 tl->order_key[0] = ~0ull;
             }
-            if (std::memcmp(tl->order_key, key, sizeof key) != 0) {             // another geometry or scene: start afresh
-                RM_HIP(ctx, hipMemsetAsync(tl->order_block, 0, 2u * (size_t)tl->order_cap * sizeof(uint32_t), stream));
-                std::memcpy(tl->order_key, key, sizeof key);
-                tl->order_frames = 0;
+            // (an entry of the list is taken by its tag: another geometry or scene, or the tags used up -> start afresh)
+            const uint32_t tag_wrap = ctx->ord_tag_wrap ? ctx->ord_tag_wrap : (1u << RM_ORD_TAG_BITS) - 1u;
+            const bool fresh = std::memcmp(tl->order_key, key, sizeof key) != 0;
+            if (fresh || tl->ord_tag >= tag_wrap) {
+                if (fresh) {
+                    RM_HIP(ctx, hipMemsetAsync(tl->order_block, 0, rm_tile_lists::order_bytes(tl->order_cap), stream));
+                    std::memcpy(tl->order_key, key, sizeof key);
+                    tl->order_frames = 0;
+                } else {
+                    RM_HIP(ctx, hipMemsetAsync(tl->list(), 0, (size_t)RM_ORD_BUCKETS * tl->order_cap * sizeof(uint32_t), stream));
+                }
+                tl->ord_tag = 0;
             }
-            const uint32_t f = tl->order_frames++;
-            a.patch_cost = tl->cost(f & 1u);
-            if (f >= 1u) {                                                      // the previous launch's counters -> the next launch's order
-                a.sort_cost = tl->cost((f + 1u) & 1u);
-                a.sort_order = tl->order((f + 1u) & 1u);
-                a.sort_block = 1u;
-                grid.x += 1u;
-            }
-            if (f >= 2u) a.patch_order = tl->order(f & 1u);                     // sorted by the launch before from the counters of the one before that
-            // Sky tail.  The head of every launch marks the patches nothing can be hit in, the sorter puts them last and
-            // writes how many the others are into page-locked memory.  While the VIEW is the one those frames had, the sky
-            // patches at the end of the order get one wave each instead of sixteen (the dispatcher takes ~0.7 ns per wave
-            // that looks at its word, stores its zeros and leaves: half of a Cornell launch).  Only the launch's geometry is
-            // carried over: each of those waves looks at THIS launch's classification of its patch and renders it where it
-            // is not sky after all.
             if (!tl->hint) {
-                RM_HIP(ctx, hipHostMalloc((void **)&tl->hint, sizeof(unsigned long long), hipHostMallocDefault));
-                *tl->hint = 0ull;
-                RM_HIP(ctx, hipMalloc((void **)&tl->ov_block, (2u * RM_OV_WORDS + RM_TAIL_ROLES) * sizeof(uint32_t)));
-                RM_HIP(ctx, hipMemsetAsync(tl->ov_block, 0, (2u * RM_OV_WORDS + RM_TAIL_ROLES) * sizeof(uint32_t), stream));
+                RM_HIP(ctx, hipHostMalloc((void **)&tl->hint, 2u * sizeof(unsigned long long), hipHostMallocDefault));
+                tl->hint[0] = tl->hint[1] = 0ull;
             }
-            if (*(volatile unsigned long long *)tl->hint == ~0ull)
-                return ctx_fail(ctx, RM_ERR_HIP, "render: the sky tail's hand-over timed out in an earlier launch on this stream (that frame is void)");
+            // (a wave of an earlier launch gave up a wait that cannot fail: that frame is void -- said once)
+            if (rm_status vst = void_frame_check(ctx, "render")) return vst;
+            const uint32_t f = tl->order_frames++;
             const uint32_t seq = ++tl->seq;
             if (f == 0u) tl->key_seq0 = seq;
             const double view[7] = {ctx->camera.x, ctx->camera.y, ctx->camera.z, p->half_fov, p->height, p->width, p->ratio};
@@ -1174,82 +1199,95 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 std::memcpy(tl->view, view, sizeof view);
                 tl->view_seq0 = seq;
             }
-            a.sort_hint = tl->hint;
+            const bool timed = n_patches <= ctx->patch_order_max;             // (larger launches are many rounds deep: by place, for the sky tail alone)
+            a.ord_ctl = tl->ctl(f & 1u);
+            a.ord_ctl_next = tl->ctl((f + 1u) & 1u);
+            a.ord_list = tl->list();
+            a.ord_cap = tl->order_cap;
+            a.ord_tag = ++tl->ord_tag;
+            a.sig_cur = tl->sig(f & 1u);
+            a.sig_prev = tl->sig((f + 1u) & 1u);
+            a.patch_cost = timed ? tl->cost(f & 1u) : nullptr;
+            a.cost_prev = timed ? tl->cost((f + 1u) & 1u) : nullptr;
+            a.ctab = tl->ctab((f + 1u) & 1u);
+            a.ctab_next = timed ? tl->ctab(f & 1u) : nullptr;
+            // what the patches are ordered by: the previous frame's times by place while the view is the one that frame had; else
+            // the cost of what a patch can reach, once a table exists (written by the launch before from the launch before that)
+            a.key_mode = !timed || f == 0u || ctx->order_keys == 0 ? RM_KEY_PLACE
+                       : (seq > tl->view_seq0 && ctx->order_keys != 2) ? RM_KEY_COST
+                       : (f >= 2u && a.mask_exact && ctx->order_keys != 1) ? RM_KEY_CONTENT : RM_KEY_PLACE;
+            a.ord_hint = tl->hint;
+            a.err_word = tl->hint + 1;
             a.launch_seq = seq;
-            a.ov_zero = tl->ov_block + ((seq + 1u) & 1u) * RM_OV_WORDS;   // (the next launch's block: cleared by this launch's sorting workgroup)
-            a.order_by_place = n_patches > ctx->patch_order_max ? 1u : 0u;
-            if (ctx->sky_tail && a.cls_blocks && a.patch_order) {
-                uint32_t tail = 0, keep = 0;
+            a.cls_tally = a.cls_blocks + (ctx->test_stall_order ? 1u : 0u);       // (test hook: a tally that never completes)
+            // Sky tail.  The last classifying workgroup of every launch tells the host how many of the ordered patches had
+            // something to hit (page-locked memory, read here without a wait).  The places behind them -- the sky -- get one wave
+            // each instead of sixteen (the dispatcher takes ~0.7 ns per wave that finds out that its tile is sky: half of a
+            // Cornell launch).  From a frame of THIS view the count is exact; from an earlier view it is a guess, and the places
+            // it gets wrong -- the tail's first -- are rendered by sixteen waves each behind the grid's end.
+            uint32_t tail = 0, cap = 0;
+            if (ctx->sky_tail) {
                 bool guess = false;
                 if (ctx->sky_tail_force >= 0) {                                 // (test hook: a hint that is wrong)
-                    tail = std::min((uint32_t)ctx->sky_tail_force, n_patches);
+                    tail = std::min((uint32_t)ctx->sky_tail_force, n_dyn);
                     guess = true;
-                } else if (seq >= tl->key_seq0 + 2u) {
-                    // (the order in use was sorted from the frame two launches back, the hint from the frame before its
-                    // sorter's launch: frames of this view -> the hint is exact; of this scene and frame geometry, the view
-                    // has moved since -> it is a guess, and what it gets wrong is handed on to waves at the grid's end)
+                } else {
                     const unsigned long long h = *(volatile unsigned long long *)tl->hint;
                     const uint32_t h_seq = (uint32_t)(h >> 32), n_lit = (uint32_t)h;
-                    const bool exact = seq >= tl->view_seq0 + 2u && h_seq >= tl->view_seq0 + 1u;
-                    guess = !exact;
-                    if ((exact || ctx->sky_tail_motion) && h_seq >= tl->key_seq0 + 1u && h_seq < seq && n_lit <= n_patches) tail = n_patches - n_lit;
-                    // (a guess only where the sky is most of the frame: there the tail is a third of the launch -- Cornell box,
-                    // camera on the move, 40.0 -> 35.5 us -- and a camera that jumps hands on a few dozen patches; where it is half
-                    // of the frame the tail buys 1 % and a jump that turns more patches than the hand-over has room for leaves them
-                    // to single waves: demo scene 86 -> 208 us a frame with a jump every few frames)
-                    if (guess && ctx->sky_tail_force < 0 && 5u * (uint64_t)tail < 3u * (uint64_t)n_patches) tail = 0u;
-                    // (the last sky patches keep their sixteen waves: short waves that fill the launch's drain)
-                    tail -= std::min(tail, (uint32_t)ctx->sky_tail_keep);
+                    const bool valid = h_seq >= tl->key_seq0 && h_seq < seq && h != 0ull && n_lit <= n_dyn;
+                    guess = h_seq < tl->view_seq0;
+                    if (valid && (!guess || ctx->sky_tail_motion)) tail = n_dyn - n_lit;
                     if (tail < 8u) tail = 0u;
-                    keep = (n_patches - n_lit) - tail;
                 }
-                a.tail_patches = tail;
-                a.tail_first = n_patches - tail - (tail ? keep : 0u);
-                grid.x -= 15u * tail;
-                if (tail && guess && tail <= RM_TAIL_ROLES) {
-                    a.tail_role = tl->ov_block + 2u * RM_OV_WORDS;
-                    a.ov_cap = std::min(tail, std::min(RM_OV_PATCHES, std::max(128u, n_patches / 8u)));
-                    a.ov_ctl = tl->ov_block + (seq & 1u) * RM_OV_WORDS;
-                    grid.x += 16u * a.ov_cap;
-                    // (the kernel with the hand-over: a kernel of its own -- its code costs the waves that render 2-3 %)
-                    fn = rm_pick_kernel(k.fast, k.staged, k.bvh, k.cull, k.edges, 2, false, k.stack, k.pow_mode);
-                    if (!fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel with the hand-over for this scene / depth combination");
-                }
-                // (dealt out evenly among the tile waves behind the launch's first round: rm_render_kernel.inc)
-                const uint64_t head_ids = a.n_tiles - 16u * tail, behind = head_ids - std::min<uint64_t>(a.first_round, head_ids);
-                a.tail_q = (tail && behind) ? (uint32_t)((((uint64_t)tail << 32) + behind + tail - 1u) / (behind + tail)) : 0u;
-                // Launches of up to 4,096 patches: the tail BEHIND every tile wave instead (same box: Cornell 32.7 -> 31.4 us, demo
-                // 69.2 -> 68.5 -- a tile with something to hit never waits for a slot behind a wave that only stores, and the
-                // tail's stores, 24-43 MB, overlap the drain); an 8K launch ends with 380 MB of them if they wait: 960 -> 1,020 us.
-                if (a.tail_q > 1u && (ctx->sky_tail_place == 2 || (ctx->sky_tail_place == 0 && !a.order_by_place))) a.tail_q = 1u;
+                // (room to hand on: a press of the reference's buttons turns a few hundred of a 1080p frame's 1,980 patches)
+                if (tail && guess) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : std::max(512u, n_patches / 16u));
             }
+            a.tail_patches = tail;
+            a.ov_cap = cap;
+            grid.x = a.cls_blocks + a.n_static + 16u * (n_dyn - tail) + tail + 16u * cap;
+            // (dealt out evenly among the tile waves behind the launch's first round: rm_render_kernel.inc)
+            const uint64_t behind = 16ull * (n_dyn - tail);
+            a.tail_q = (tail && behind) ? (uint32_t)((((uint64_t)tail << 32) + behind + tail - 1u) / (behind + tail)) : 0u;
+            // Launches of up to 4,096 patches: the tail BEHIND every tile wave instead (same box: Cornell 32.7 -> 31.4 us, demo
+            // 69.2 -> 68.5 -- a tile with something to hit never waits for a slot behind a wave that only stores, and the
+            // tail's stores, 24-43 MB, overlap the drain); an 8K launch ends with 380 MB of them if they wait: 960 -> 1,020 us.
+            if (a.tail_q > 1u && (ctx->sky_tail_place == 2 || (ctx->sky_tail_place == 0 && timed))) a.tail_q = 1u;
         }
     }
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     unsigned long long *d_stamps = nullptr;
     const size_t n_waves = (size_t)grid.x * m.waves;
-    RM_HIP(ctx, hipMalloc(&d_stamps, n_waves * 32));
-    RM_HIP(ctx, hipMemsetAsync(d_stamps, 0, n_waves * 32, stream));
+    RM_HIP(ctx, hipMalloc(&d_stamps, n_waves * 48));
+    RM_HIP(ctx, hipMemsetAsync(d_stamps, 0, n_waves * 48, stream));
     a.debug_stamps = d_stamps;
 #endif
     void *args[] = {(void *)&ctx->d_scene, (void *)&a, (void *)&d_frame};
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
     ctx->last_launch_grid = grid.x;
     ctx->last_launch_tail = a.tail_patches;
-    if (a.ov_cap && std::getenv("RM_DEBUG_TAIL")) {                     // (diagnostic: waits for the launch)
-        uint32_t c[2] = {0u, 0u};
+    if (a.ord_ctl && std::getenv("RM_DEBUG_TAIL")) {                    // (diagnostic: waits for the launch)
+        uint32_t c[RM_ORD_CTL_WORDS] = {};
         RM_HIP(ctx, hipStreamSynchronize(stream));
-        RM_HIP(ctx, hipMemcpy(c, a.ov_ctl, sizeof c, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[rm_tail] launch %u: tail %u patches, room for %u to hand on, %u handed on, %u decided\n", a.launch_seq, a.tail_patches, a.ov_cap, c[0], c[1]);
+        RM_HIP(ctx, hipMemcpy(c, a.ord_ctl, sizeof c, hipMemcpyDeviceToHost));
+        uint32_t lit = 0;
+        for (uint32_t b = 0; b < RM_ORD_SKY; b++) lit += c[b];
+        std::fprintf(stderr, "[rm_order] launch %u keys %u: first round %u waves, %u + %u sky places; tail %u, room to hand on %u, handed on %u; buckets", a.launch_seq, a.key_mode,
+                     a.n_static, lit, c[RM_ORD_SKY], a.tail_patches, a.ov_cap, a.tail_patches > c[RM_ORD_SKY] ? std::min(a.ov_cap, a.tail_patches - c[RM_ORD_SKY]) : 0u);
+        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) std::fprintf(stderr, " %u", c[b]);
+        std::fprintf(stderr, "\n");
     }
     if (fb) fb->cur = (fb->cur + 1) % 3;
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     RM_HIP(ctx, hipStreamSynchronize(stream));
     if (const char *path = std::getenv("RM_DEBUG_STAMPS")) {
-        std::fprintf(stderr, "stamps: grid %u cls_blocks %u sort_block %u n_tiles %u tail_patches %u tail_q %u\n", grid.x, a.cls_blocks, a.sort_block, a.n_tiles, a.tail_patches, a.tail_q);
+        std::fprintf(stderr, "stamps: grid %u cls_blocks %u n_static %u n_tiles %u tail_patches %u tail_q %u ov_cap %u key_mode %u\n", grid.x, a.cls_blocks, a.ord_ctl ? a.n_static : 0u, a.n_tiles, a.tail_patches, a.tail_q, a.ov_cap, a.key_mode);
         std::vector<unsigned long long> h(n_waves * 4);
         RM_HIP(ctx, hipMemcpy(h.data(), d_stamps, n_waves * 32, hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+        // (<path>.ext: per wave the tile it rendered and the tile's classification word)
+        std::vector<unsigned long long> x(n_waves * 2);
+        RM_HIP(ctx, hipMemcpy(x.data(), d_stamps + n_waves * 4, n_waves * 16, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen((std::string(path) + ".ext").c_str(), "wb")) { std::fwrite(x.data(), 8, x.size(), f); std::fclose(f); }
     }
     RM_HIP(ctx, hipFree(d_stamps));
 #endif
@@ -1338,6 +1376,7 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     } else {
         RM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (rm_status vst = void_frame_check(ctx, "rm_render")) return vst;
     if (timing) {
         float ms = 0.f;
         RM_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -1359,8 +1398,7 @@ rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t
     st = choose_kernel(ctx, params, band.count() * (params->frame_width / RM_PATCH_SIZE) * 16u, &k);
     if (st != RM_OK) return st;
     // the name rocprofv3's kernel trace shows (template arguments in declaration order)
-    // (the last one, HANDON: the kernel of a launch whose sky tail is sized by a guess -- not what a settled render loop launches)
-    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s, false>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
+    std::snprintf(buf, buflen, "%s::rm_render_static<%d, %d, %d, %d, %s, %s, %s, %s, %s, %s>", k.fast ? "rmdev_fast" : "rmdev_strict", k.stack,
                   k.pow_mode, k.mode.waves, k.mode.per_wave, k.staged ? "true" : "false", k.bvh ? "true" : "false",
                   k.cull ? "true" : "false", k.edges ? "true" : "false", k.order ? "true" : "false", k.feedback ? "true" : "false");
     return RM_OK;

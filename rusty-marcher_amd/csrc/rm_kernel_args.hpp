@@ -9,9 +9,14 @@
 #include "rm_internal.h"
 
 #define RM_BVH_NODE_WORDS 16u
-// patches a tail whose hint is a guess can hand on to waves at the grid's end; the block: count, tally, list
-#define RM_OV_PATCHES 512u
-#define RM_OV_WORDS (2u + RM_OV_PATCHES)
+// dispatch order built at the launch's head (KernelArgs::ord_*): sixteen buckets, the last one the sky
+#define RM_ORD_BUCKETS 16u
+#define RM_ORD_SKY 15u
+#define RM_ORD_CTL_WORDS 32u            /* [0..15] counts, [16] tally */
+#define RM_ORD_TAG_BITS 12u
+#define RM_ORD_PATCH_BITS 20u
+#define RM_CTAB_WORDS 64u
+enum { RM_KEY_PLACE = 0, RM_KEY_COST = 1, RM_KEY_CONTENT = 2 };
 
 // waves per SIMD the integer-power kernels are compiled for (register budget 512 / this)
 #ifndef RM_MIN_WAVES
@@ -85,35 +90,41 @@ struct KernelArgs {
     uint32_t mask_tag;
     uint32_t cls_blocks;
     uint32_t cls_prims;
-    // Patch order (rm_device.hip, launches of up to 4,096 patches without the tile-level feedback): every wave
-    // adds its tile's time to its 32x32 patch's counter; ONE workgroup at the head of the next launch on the
-    // stream sorts the patches by that (a counting sort over 64 buckets), and the launch after dispatches
-    // them longest first.  Only the order of dispatch is carried over.  NULL: off / no history yet.
-    const uint32_t *patch_order;             // this launch: the k-th 16 ids render patch patch_order[k]
-    uint32_t *patch_cost;                    // this launch adds here: 100 MHz ticks per patch
-    const uint32_t *sort_cost;               // the previous launch's counters: sorted into ...
-    uint32_t *sort_order;                    // ... the next launch's order by this launch's sorting workgroup, then cleared
-    uint32_t sort_block;                     // 1: the workgroup behind the classifying ones sorts
-    // Sky tail: the classification at the head of a launch marks the patches nothing can be hit in (bit 31 of their
-    // counters), the sorter puts them last and tells the host how many the others are (page-locked memory: a hint, read
-    // without a wait); while the view stays the same the next launches give the last tail_patches patches of the order
-    // ONE wave each, which looks at this launch's own classification: sky -> 24 KB of zeros; not sky (a stale hint) ->
-    // the wave renders the patch's sixteen tiles itself.  0: every patch gets its sixteen waves.
+    // Dispatch order from THIS launch's classification (rm_classify.inc `place_patch`, rm_render_kernel.inc `order_entry`).
+    // The reference renders only after the camera has moved (main.rs:74-78), so an order kept from earlier frames BY PLACE is
+    // stale exactly when it is needed.  Instead the classifying workgroups at the launch's head, which know what each patch's
+    // primary rays can reach, put every patch behind the launch's first round into one of sixteen buckets -- by what the
+    // patch's longest tile cost in the previous frame while the view stands still, else by what patches reaching the same
+    // primitives cost in earlier frames (cost by content: it moves with the picture), the sky last -- with one atomic each;
+    // a render wave behind the first round takes the k-th patch of the buckets laid end to end once every classifying
+    // workgroup has said it is done (ord_ctl[16]).  The first round -- the waves resident at once -- renders the bottom rows
+    // by place and waits for nobody.  Only the order of dispatch depends on any of it.  ord_ctl == NULL: off.
+    uint32_t *ord_ctl;                       // this launch: [0..15] patches per bucket, [16] classifying workgroups done
+    uint32_t *ord_ctl_next;                  // the next launch's block: cleared by the last classifying workgroup of this one
+    uint32_t *ord_list;                      // RM_ORD_BUCKETS x ord_cap entries: (ord_tag << 20) | patch
+    uint32_t ord_cap;                        // entries per bucket (the patches behind the first round)
+    uint32_t ord_tag;                        // 1..4095: an entry is there once it carries this launch's tag
+    uint32_t n_static;                       // waves of the first round (a multiple of 16): the bottom rows by place
+    uint32_t key_mode;                       // RM_KEY_PLACE / RM_KEY_COST / RM_KEY_CONTENT
+    uint32_t *patch_cost;                    // this launch's waves: their tile's time -> max per patch (100 MHz ticks); NULL: tiles are not timed
+    uint32_t *cost_prev;                     // the previous launch's (same geometry, same scene); cleared for the next launch by this one's last classifying workgroup
+    unsigned long long *sig_cur;             // per patch: the primitives its tiles' primary rays can reach (this launch writes)
+    const unsigned long long *sig_prev;      // ... of the previous launch
+    const uint32_t *ctab;                    // cost by content: [pid] mean cost of the patches that could reach the primitive (0: not seen), from the launch before
+    uint32_t *ctab_next;                     // ... written by this launch's last classifying workgroup from (sig_prev, cost_prev)
+    // Sky tail: the last tail_patches places of the order get ONE wave each instead of sixteen -- sized by the host from a HINT
+    // (how many patches the previous frames found nothing to hit in: ord_hint, page-locked, read without a wait).  Such a wave
+    // finds its place's bucket: sky -> 24 KB of zeros.  Where the hint was a guess (the view has moved) and more patches have
+    // something to hit than it said, the first of the tail's places hold such patches: place tail_first + j is rendered by the
+    // sixteen waves j * 16 .. j * 16 + 15 behind the grid's end while j < ov_cap, by its own wave, tile by tile, beyond that.
     uint32_t tail_patches;
-    uint32_t tail_first;                     // the tail: patches [tail_first, tail_first + tail_patches) of the order (sky patches behind it keep their sixteen waves: they fill the launch's drain)
-    // ... and where the view has MOVED since the frames the hint came from (it is then a guess): the workgroup that classifies a
-    // patch of the tail and finds something to hit in it hands the patch to sixteen waves at the very end of the grid (ov_cap
-    // patches of them; the list is ov_ctl[2..], its count ov_ctl[0]; ov_ctl[1] counts the classifying workgroups that are
-    // done), or back to the tail's own wave when that list is full.  ov_zero: the next launch's block, cleared by this
-    // launch's sorting workgroup.
-    uint32_t *ov_ctl, *ov_zero;              // RM_OV_WORDS u32 each
-    uint32_t *tail_role;                     // per patch of the tail: (launch_seq << 2) | 1 handed on / 2 the tail's wave renders it
     uint32_t ov_cap;
-    uint32_t first_round;                    // workgroups resident at once: they do not wait for their tiles' classification; a large launch's sky tail is dealt out behind them
-    uint32_t order_by_place;                 // launches of more than 4,096 patches: no tile is timed, the order is bottom-up less the sky (which goes to the tail)
-    unsigned long long *sort_hint;           // (launch_seq << 32) | patches with something to hit, written by the sorter
+    uint32_t first_round;                    // workgroups resident at once: they do not wait for their tiles' classification
+    uint32_t tail_q;                         // ceil(tail_patches 2^32 / (tail_patches + tile waves behind the first round)); 1: the tail behind every tile wave; 0: no such waves
+    unsigned long long *ord_hint;            // (launch_seq << 32) | patches behind the first round with something to hit
+    unsigned long long *err_word;            // page-locked: non-zero once a wave of a launch on this stream gave up a wait that cannot fail (the frame is void)
     uint32_t launch_seq;
-    uint32_t tail_q;                         // ceil(tail_patches 2^32 / (tail_patches + tile waves behind the first round)), 0: no such waves
+    uint32_t cls_tally;                      // classifying workgroups the waves wait for (= cls_blocks; a test hook overstates it)
 };
 
 // What the classification launch gets besides the render launch's own arguments.
@@ -154,6 +165,6 @@ struct StackEntry {
 
 // The kernel of a launch (rm_kernels.hip, compiled once per numeric flavour and kernel group):
 // stack 4 / 8 / 16 / 32, pow_mode POW_GENERIC / POW_INTEGER.  NULL: no such instantiation.
-const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, int order, bool feedback, int stack, int pow_mode);   // order: 0 off, 1 the patch order, 2 ... with the hand-over of a guessed tail
+const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edges, int order, bool feedback, int stack, int pow_mode);   // order: 0 off, 1 the dispatch order from the launch's own classification
 
 #endif

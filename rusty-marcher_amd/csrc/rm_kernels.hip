@@ -19,12 +19,12 @@ using namespace rmdev;
 
 namespace {
 
-template <bool STAGED, bool BVH, bool CULL, bool EDGES, bool ORDER, bool FB, bool HANDON = false>
+template <bool STAGED, bool BVH, bool CULL, bool EDGES, bool ORDER, bool FB>
 const void *pick(int stack, int pow_mode) {
 #define RM_ROW(S)                                                                                                            \
     if (stack == S)                                                                                                          \
-        return pow_mode == POW_INTEGER ? (const void *)flavour::rm_render_static<S, POW_INTEGER, 1, 1, STAGED, BVH, CULL, EDGES, ORDER, FB, HANDON> \
-                                       : (const void *)flavour::rm_render_static<S, POW_GENERIC, 1, 1, STAGED, BVH, CULL, EDGES, ORDER, FB, HANDON>;
+        return pow_mode == POW_INTEGER ? (const void *)flavour::rm_render_static<S, POW_INTEGER, 1, 1, STAGED, BVH, CULL, EDGES, ORDER, FB> \
+                                       : (const void *)flavour::rm_render_static<S, POW_GENERIC, 1, 1, STAGED, BVH, CULL, EDGES, ORDER, FB>;
     RM_ROW(4) RM_ROW(8) RM_ROW(16) RM_ROW(32)
 #undef RM_ROW
     return nullptr;
@@ -40,15 +40,17 @@ const void *pick(int stack, int pow_mode) {
 #define RM_PICK_NAME RM_PICK_CAT(strict, RM_KERNEL_GROUP)
 #endif
 
-// (ORDER -- the patch-order feedback of small launches -- in every group but the one with the tile-level feedback)
+// (ORDER -- the dispatch order from the launch's own classification -- in every group but the one with the tile-level feedback)
 template <bool STAGED, bool BVH, bool CULL, bool FB>
-static const void *pick_eo(bool edges, int order, int stack, int pow_mode) {     // order: 0 off, 1 the patch order, 2 ... with the hand-over of a guessed tail
-    if (FB) return edges ? pick<STAGED, BVH, CULL, true, false, FB>(stack, pow_mode) : pick<STAGED, BVH, CULL, false, false, FB>(stack, pow_mode);
-    if (CULL && edges)
-        return order == 2 ? pick<STAGED, BVH, CULL, CULL, true, false, true>(stack, pow_mode)
-             : order ? pick<STAGED, BVH, CULL, CULL, true, false>(stack, pow_mode) : pick<STAGED, BVH, CULL, CULL, false, false>(stack, pow_mode);
-    return order == 2 ? pick<STAGED, BVH, CULL, false, true, false, true>(stack, pow_mode)
-         : order ? pick<STAGED, BVH, CULL, false, true, false>(stack, pow_mode) : pick<STAGED, BVH, CULL, false, false, false>(stack, pow_mode);
+static const void *pick_eo(bool edges, int order, int stack, int pow_mode) {     // order: 0 off, 1 on
+    if constexpr (FB) {
+        return edges ? pick<STAGED, BVH, CULL, true, false, true>(stack, pow_mode) : pick<STAGED, BVH, CULL, false, false, true>(stack, pow_mode);
+    } else {
+        if constexpr (CULL) {
+            if (edges) return order ? pick<STAGED, BVH, CULL, true, true, false>(stack, pow_mode) : pick<STAGED, BVH, CULL, true, false, false>(stack, pow_mode);
+        }
+        return order ? pick<STAGED, BVH, CULL, false, true, false>(stack, pow_mode) : pick<STAGED, BVH, CULL, false, false, false>(stack, pow_mode);
+    }
 }
 
 const void *RM_PICK_NAME(bool edges, int order, int stack, int pow_mode) {

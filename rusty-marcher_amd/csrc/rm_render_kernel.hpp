@@ -34,6 +34,13 @@ __device__ __forceinline__ uint32_t fb_edge(uint32_t b) { return (4u + (b & 3u))
 __device__ __forceinline__ double own_sgpr(double v) { double r; asm("s_mov_b64 %0, %1" : "=s"(r) : "s"(v)); return r; }
 __device__ __forceinline__ uint32_t own_sgpr(uint32_t v) { uint32_t r; asm("s_mov_b32 %0, %1" : "=s"(r) : "s"(v)); return r; }
 
+// A value every lane holds alike (read from one address, or handed back by a function that is not inlined), moved to scalar
+// registers: what is computed from it stays on the scalar unit, loops over it are scalar loops.
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
+}
+
 extern __shared__ double rm_lds[];
 
 // Every workgroup keeps its own copy of the scene in LDS; all later reads are
@@ -56,14 +63,6 @@ __device__ __forceinline__ uint32_t tile_of_id(const KernelArgs &a, uint32_t id)
     return (a.order_mul == 1u && a.order_add == 0u) ? id
          : (a.order_mul == last && a.order_add == last) ? last - id
          : (uint32_t)(((unsigned long long)id * a.order_mul + a.order_add) % a.n_tiles);
-}
-
-// ... or, with a patch order from the previous frames on the stream (rm_device.hip), the patches longest first
-__device__ __forceinline__ uint32_t tile_for(const KernelArgs &a, uint32_t id) {
-    // (sky tail: the patches [tail_first, tail_first + tail_patches) of the order are not these waves')
-    uint32_t k = id >> 4;
-    k += (a.tail_patches && k >= a.tail_first) ? a.tail_patches : 0u;
-    return a.patch_order ? a.patch_order[k] * 16u + (15u - (id & 15u)) : tile_of_id(a, id);
 }
 
 // tile -> pixel origin.  Patch-major: patch = tile / 16 walks the band row by row

@@ -742,75 +742,93 @@ def test_tile_classification_is_bitwise_invisible(pkg, O, monkeypatch):
 
 
 def test_patch_order_renders_every_tile_once(pkg, monkeypatch):
-    """Patch order (rm_device.hip): every wave adds its tile's time to its patch's counter, one workgroup of the next
-    launch sorts the patches by that, and the launch after dispatches them longest first.  Only the ORDER of dispatch
-    may change: every frame of a sequence on one stream -- the same camera for several frames (counters, then an
-    order from them), a moved camera, another size, a band, another scene and back -- must equal the frame of a
-    context without it bit for bit, f64 and display bytes, in buffers pre-filled with a sentinel (a patch missing
-    from the order, or in it twice, would show)."""
+    """Dispatch order from the launch's own classification (rm_classify.inc place_patch, rm_render_kernel.inc order_entry):
+    the classifying workgroups at a launch's head put every patch behind the first round into a bucket -- by the previous
+    frame's tile times while the view stands, by the cost of what the patch can reach once it has moved, by place where
+    there is nothing to go by -- and the render waves take the k-th patch of the buckets laid end to end.  Only the ORDER
+    of dispatch may change: every frame of a sequence on one stream -- the same camera for several frames, a moved camera,
+    another size, a band, another scene and back -- must equal the frame of a context without it bit for bit, f64 and
+    display bytes, in buffers pre-filled with a sentinel (a patch missing from the order, or in it twice, would show).
+    RM_FIRST_ROUND makes the first round small enough for frames of a few thousand tiles to have an order at all."""
     import torch
     monkeypatch.setenv("RM_PATCH_ORDER", "0")
     plain = pkg.backend.Context(0)
     monkeypatch.setenv("RM_PATCH_ORDER", "1")
     monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
-    ordered = pkg.backend.Context(0)
+    ctxs = {}
+    for name, env in (("default", {}), ("round256", {"RM_FIRST_ROUND": "256"}), ("round0", {"RM_FIRST_ROUND": "0"}),
+                      ("by_place", {"RM_FIRST_ROUND": "64", "RM_ORDER_KEYS": "0"}), ("by_time", {"RM_FIRST_ROUND": "64", "RM_ORDER_KEYS": "1"}),
+                      ("by_content", {"RM_FIRST_ROUND": "64", "RM_ORDER_KEYS": "2"}),
+                      ("tags_wrap", {"RM_FIRST_ROUND": "128", "RM_ORD_TAG_WRAP": "3"}), ("no_tail", {"RM_FIRST_ROUND": "128", "RM_SKY_TAIL": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctxs[name] = pkg.backend.Context(0)
+        for k in env:
+            monkeypatch.delenv(k)
     monkeypatch.setenv("RM_TILE_CLASSIFY", "0")
-    ordered_unclassified = pkg.backend.Context(0)
+    ctxs["unclassified"] = pkg.backend.Context(0)
     monkeypatch.delenv("RM_TILE_CLASSIFY")
     monkeypatch.delenv("RM_PATCH_ORDER")
     demo = pkg.Scene.create_default()
     cornell = workloads.product_scene(pkg, "cornell")
     seq = [(demo, (0., 0., 0.), 640, 352, 5, None)] * 4 + [(demo, (0., 5., 0.), 640, 352, 5, None)] * 2 + \
+          [(demo, c, 640, 352, 5, None) for c in workloads.camera_walk()[:10]] + \
           [(demo, (0., 5., 0.), 800, 608, 4, None)] * 3 + [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 3 + \
-          [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 3 + [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 4
+          [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 3 + [(cornell, (5., 0., 5.), 640, 352, 3, None)] * 2 + \
+          [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 3 + [(demo, (6., 0., 1.), 1920, 1080, 5, None), (demo, (6., 5., 1.), 1920, 1080, 5, None)]
     try:
         for k, (scene, cam, w, h, depth, band) in enumerate(seq):
             scene.camera = pkg.Vec3f(*cam)
             p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
             p.flags = _FLAGS["value"]
-            outs = []
-            for c in (plain, ordered, ordered_unclassified):
+            outs = {}
+            for name, c in [("plain", plain)] + list(ctxs.items()):
+                if os.environ.get("RM_TEST_TRACE"):
+                    print("frame", k, name, cam, w, h, depth, band, flush=True)
                 c.upload(scene.flatten())
                 f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
                 u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
                 torch.cuda.synchronize()
                 c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
                 torch.cuda.synchronize()
-                outs.append((f64.cpu().numpy(), u8.cpu().numpy()))
-            for j in (1, 2):
-                assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the patch order on (%d)" % (k, j)
-                assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
+                outs[name] = (f64.cpu().numpy(), u8.cpu().numpy())
+            for name in ctxs:
+                assert outs["plain"][0].tobytes() == outs[name][0].tobytes(), "frame %d of the sequence: f64 differs with the dispatch order on (%s)" % (k, name)
+                assert np.array_equal(outs["plain"][1], outs[name][1]), "frame %d: display bytes differ (%s)" % (k, name)
             if band is None:
-                assert not (outs[1][0][:h // 32 * 32] == -1.).any()
+                assert not (outs["default"][0][:h // 32 * 32] == -1.).any()
     finally:
         plain.close()
-        ordered.close()
-        ordered_unclassified.close()
+        for c in ctxs.values():
+            c.close()
 
 
 def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
-    """Sky tail (rm_device.hip): patches that the previous frames of a view found nothing to hit in get one wave instead
-    of sixteen; that wave looks at THIS launch's classification of its patch, stores the primary-miss value when it
-    still says sky and renders the patch itself when it does not.  Only the launch's geometry may be carried over: every
-    frame of a sequence on one stream -- a view held for several frames (the tail arms itself), a moved camera, bands,
-    display bytes, another scene -- must equal the frame of a context without it bit for bit in buffers pre-filled
-    with a sentinel; so must the frames of contexts whose hint is WRONG (RM_SKY_TAIL_FORCE: the last 37 patches of the
-    order, or every patch, taken for sky whatever the classification of the earlier frames said)."""
+    """Sky tail (rm_device.hip): the places of the dispatch order that hold patches nothing can be hit in get one wave instead
+    of sixteen -- how many, the host takes from a hint the earlier launches left in page-locked memory.  From a frame of the
+    view being rendered the count is exact; from an earlier view it is a guess, and the places it gets wrong are rendered by
+    sixteen waves each behind the grid's end (while there is room: RM_SKY_TAIL_CAP) or by the tail's own wave, tile by tile.
+    Only the launch's geometry may be carried over: every frame of a sequence on one stream -- a view held for several frames
+    (the tail arms itself), a moved camera, bands, display bytes, another scene -- must equal the frame of a context without
+    it bit for bit in buffers pre-filled with a sentinel; so must the frames of contexts whose hint is WRONG (RM_SKY_TAIL_FORCE:
+    the last 37 places of the order, or every place, taken for sky whatever the earlier frames said), with room to hand on
+    all, some or none of them."""
     import torch
     monkeypatch.setenv("RM_PATCH_ORDER", "1")
     monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    monkeypatch.setenv("RM_FIRST_ROUND", "256")                     # (frames of a few hundred patches: all but sixteen of them have a place in the order)
     monkeypatch.setenv("RM_SKY_TAIL", "0")
     plain = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL", "1")
-    monkeypatch.setenv("RM_SKY_TAIL_KEEP", "0")                     # (frames of a few hundred patches: every sky patch to the tail)
     monkeypatch.setenv("RM_SKY_TAIL_MOTION", "0")                   # (no guesses: a hint only from frames of the view being rendered)
     tail = pkg.backend.Context(0)
     monkeypatch.delenv("RM_SKY_TAIL_MOTION")
-    moving = pkg.backend.Context(0)                                 # (the default: a moved view takes the hint as a guess where the sky is most of the frame: the Cornell box)
-    monkeypatch.setenv("RM_SKY_TAIL_KEEP", "16")                    # (the last sixteen sky patches keep their sixteen waves,
-    monkeypatch.setenv("RM_SKY_TAIL_PLACE", "even")                 # the tail's waves dealt out among the tile waves, not behind them)
-    tail_keep = pkg.backend.Context(0)
+    moving = pkg.backend.Context(0)                                 # (the default: a moved view takes the hint as a guess)
+    monkeypatch.setenv("RM_SKY_TAIL_PLACE", "even")                 # (the tail's waves dealt out among the tile waves, not behind them)
+    monkeypatch.setenv("RM_FIRST_ROUND", "0")
+    tail_even = pkg.backend.Context(0)
     monkeypatch.delenv("RM_SKY_TAIL_PLACE")
+    monkeypatch.setenv("RM_FIRST_ROUND", "256")
     monkeypatch.setenv("RM_PATCH_ORDER_MAX", "100")                 # (larger launches: no tile is timed, the order is bottom-up less the sky)
     monkeypatch.setenv("RM_SKY_TAIL_BIG_MIN", "0")
     by_place = pkg.backend.Context(0)
@@ -818,28 +836,35 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     monkeypatch.delenv("RM_SKY_TAIL_BIG_MIN")
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "37")
     wrong_some = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL_CAP", "5")
+    wrong_some_little_room = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL_CAP", "0")
+    wrong_some_no_room = pkg.backend.Context(0)
+    monkeypatch.delenv("RM_SKY_TAIL_CAP")
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "100000")
     wrong_all = pkg.backend.Context(0)
-    for v in ("RM_SKY_TAIL_FORCE", "RM_SKY_TAIL_KEEP", "RM_SKY_TAIL", "RM_TILE_CLASSIFY", "RM_PATCH_ORDER"):
+    for v in ("RM_SKY_TAIL_FORCE", "RM_SKY_TAIL", "RM_TILE_CLASSIFY", "RM_PATCH_ORDER", "RM_FIRST_ROUND"):
         monkeypatch.delenv(v)
     demo = pkg.Scene.create_default()
     cornell = workloads.product_scene(pkg, "cornell")
     seq = [(demo, (0., 0., 0.), 640, 352, 5, None)] * 6 + [(demo, (0., 5., 0.), 640, 352, 5, None)] * 5 + \
           [(demo, (0., 5. + k, -2. * k), 640, 352, 5, None) for k in range(4)] + \
           [(demo, (0.5 * k, 0.3 * k, -0.4 * k), 640, 352, 5, None) for k in range(8)] + \
+          [(demo, c, 640, 352, 5, None) for c in workloads.camera_walk()[:12]] + \
           [(demo, (0., 0., 0.), 800, 608, 4, (2, 17, 3))] * 5 + [(cornell, (0., 0., 0.), 640, 352, 3, None)] * 6 + \
           [(cornell, (3. * k, 2. * k, -5. * (k % 3)), 640, 352, 3, None) for k in range(1, 9)] + \
-          [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 5
-    armed = {"tail": 0, "moving": 0, "tail_keep": 0, "by_place": 0, "wrong_some": 0, "wrong_all": 0}
+          [(demo, (1., 0., 1.), 1920, 1080, 5, None)] * 4 + [(demo, (1., 0., 11.), 1920, 1080, 5, None), (demo, (1., 0., 1.), 1920, 1080, 5, None)]
+    names = ("tail", "moving", "tail_even", "by_place", "wrong_some", "wrong_some_little_room", "wrong_some_no_room", "wrong_all")
+    armed = {n: 0 for n in names}
     armed_on_a_new_view = 0
+    ctxs = (plain, tail, moving, tail_even, by_place, wrong_some, wrong_some_little_room, wrong_some_no_room, wrong_all)
     try:
         for k, (scene, cam, w, h, depth, band) in enumerate(seq):
             scene.camera = pkg.Vec3f(*cam)
             p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
             p.flags = _FLAGS["value"]
             outs = []
-            for name, c in (("plain", plain), ("tail", tail), ("moving", moving), ("tail_keep", tail_keep), ("by_place", by_place),
-                            ("wrong_some", wrong_some), ("wrong_all", wrong_all)):
+            for name, c in zip(("plain",) + names, ctxs):
                 if os.environ.get("RM_TEST_TRACE"):
                     print("frame", k, name, cam, w, h, depth, band, flush=True)
                 c.upload(scene.flatten())
@@ -854,26 +879,117 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
                     assert n_tail == 0
                 else:
                     armed[name] += n_tail > 0
-                # without guesses a hint is taken only from frames of the view being rendered: none in the first two frames of
-                # a view; with them (the default) a view that has moved keeps the tail -- what it gets wrong is handed on
-                new_view = (k < 2 or seq[k][:4] != seq[k - 1][:4] or seq[k][:4] != seq[k - 2][:4]
-                            or seq[k][5] != seq[k - 1][5] or seq[k][5] != seq[k - 2][5])
+                # without guesses a hint is taken only from frames of the view being rendered: none in the first frame of a
+                # view; with them (the default) a view that has moved keeps the tail -- what it gets wrong is handed on
+                new_view = k < 1 or seq[k][:4] != seq[k - 1][:4] or seq[k][5] != seq[k - 1][5]
                 if name == "tail" and new_view:
                     assert n_tail == 0, "frame %d (%s): %d patches in the tail of a view that is new" % (k, name, n_tail)
                 if name == "moving" and new_view:
                     armed_on_a_new_view += n_tail > 0
-            for j in (1, 2, 3, 4, 5, 6):
-                assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the sky tail on (%d)" % (k, j)
-                assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
+            for j in range(1, len(ctxs)):
+                assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d of the sequence: f64 differs with the sky tail on (%s)" % (k, names[j - 1])
+                assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%s)" % (k, names[j - 1])
             if band is None:
                 assert not (outs[1][0][:h // 32 * 32] == -1.).any()
         # the tail armed itself where a view was held, and the wrong hints were in force
-        assert armed["tail"] >= 8 and armed["tail_keep"] >= 8 and armed["by_place"] >= 8, armed
-        assert armed["moving"] > armed["tail"] and armed_on_a_new_view >= 3, (armed, armed_on_a_new_view)
-        assert armed["wrong_some"] >= 15 and armed["wrong_all"] >= 15, armed
+        assert armed["tail"] >= 8 and armed["tail_even"] >= 8 and armed["by_place"] >= 8, armed
+        assert armed["moving"] > armed["tail"] and armed_on_a_new_view >= 10, (armed, armed_on_a_new_view)
+        assert min(armed[n] for n in names if n.startswith("wrong")) >= 15, armed
     finally:
-        for c in (plain, tail, moving, tail_keep, by_place, wrong_some, wrong_all):
+        for c in ctxs:
             c.close()
+
+
+def test_a_wait_that_is_given_up_voids_the_frame_and_says_so(pkg, monkeypatch):
+    """The one wait of a render launch that has no fallback: a wave behind the first round needs its place in the
+    dispatch order, which is there once every classifying workgroup of the launch has said it is done -- they are the
+    launch's first workgroups and take microseconds.  A test hook makes the waves wait for one workgroup more than
+    there is: each gives up after 10 ms, renders nothing and says so in page-locked memory.  The asynchronous launch
+    has returned by then; the NEXT call on the stream must report the void frame (once), the synchronous calls report
+    their own, and the context must come down cleanly."""
+    import torch
+    monkeypatch.setenv("RM_PATCH_ORDER", "1")
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    monkeypatch.setenv("RM_FIRST_ROUND", "1024")
+    monkeypatch.setenv("RM_TEST_STALL_ORDER", "1")
+    c = pkg.backend.Context(0)
+    for v in ("RM_PATCH_ORDER", "RM_TILE_CLASSIFY", "RM_FIRST_ROUND", "RM_TEST_STALL_ORDER"):
+        monkeypatch.delenv(v)
+    try:
+        w, h = 640, 352
+        c.upload(pkg.Scene.create_default().flatten())
+        p = pkg.backend.make_params(workloads.FOV, float(h), float(w), 5)
+        p.flags = _FLAGS["value"]
+        f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+        u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())          # returns at once; its waves give up 10 ms later
+        torch.cuda.synchronize()
+        got = f64.cpu().numpy()
+        assert (got[:h // 32 * 32] == -1.).any(), "the stalled launch rendered every tile all the same"
+        with pytest.raises(pkg.BackendError) as e:
+            c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+        assert "void" in str(e.value)
+        # said once: the next launch is taken (and stalls like the first); a synchronous call reports its own frame
+        host = np.zeros((h, w, 3))
+        with pytest.raises(pkg.BackendError) as e:
+            c.render(p, host)
+            c.render(p, host)
+        assert "void" in str(e.value)
+        torch.cuda.synchronize()
+    finally:
+        c.close()
+
+
+def test_three_hundred_frames_of_a_camera_on_the_move(pkg, O, monkeypatch):
+    """300 launches of one geometry on one stream, the camera a press further before each (workloads.camera_walk: the
+    reference's own offsets): the tags of the tile masks (8 bits) and of the dispatch order (made to start afresh every
+    100 launches here) wrap, the keys change from times by place to cost by content and back, guessed sky tails hand
+    places on.  The last frame against the oracle; every 50th against a context that does none of it."""
+    import torch
+    monkeypatch.setenv("RM_PATCH_ORDER", "0")
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_PATCH_ORDER", "1")
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    monkeypatch.setenv("RM_FIRST_ROUND", "512")
+    monkeypatch.setenv("RM_ORD_TAG_WRAP", "100")
+    c = pkg.backend.Context(0)
+    for v in ("RM_PATCH_ORDER", "RM_TILE_CLASSIFY", "RM_FIRST_ROUND", "RM_ORD_TAG_WRAP"):
+        monkeypatch.delenv(v)
+    try:
+        w, h, depth = 800, 608, 5
+        scene = pkg.Scene.create_default()
+        c.upload(scene.flatten()); plain.upload(scene.flatten())
+        p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+        p.flags = _FLAGS["value"]
+        f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+        u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+        g64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+        g8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+        walk = workloads.camera_walk()
+        tails = 0
+        for k in range(300):
+            cam = walk[k % len(walk)] if k % 7 else walk[(k - 1) % len(walk)]     # (now and then the camera stays where it was)
+            c.set_camera(pkg.Vec3f(*cam))
+            if k % 50 == 49 or k == 299:
+                f64.fill_(-1.); u8.fill_(201)
+                torch.cuda.synchronize()
+            c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())
+            tails += c.launch_stats()[1] > 0
+            if k % 50 == 49 or k == 299:
+                plain.set_camera(pkg.Vec3f(*cam))
+                plain.render_device_u8(p, g64.data_ptr(), g8.data_ptr())
+                torch.cuda.synchronize()
+                assert f64.cpu().numpy().tobytes() == g64.cpu().numpy().tobytes(), "frame %d differs" % k
+                assert torch.equal(u8, g8), "frame %d: display bytes differ" % k
+        assert tails >= 100, tails
+        os_ = O.OracleScene.create_default()
+        os_.set_camera(cam)
+        compare(f64.cpu().numpy()[:h // 32 * 32], O.render(os_, w, h, max_depth=depth)[:h // 32 * 32])
+    finally:
+        plain.close()
+        c.close()
 
 
 def test_feedback_order_renders_every_tile_once(pkg, ctx, monkeypatch):

@@ -40,6 +40,36 @@ CONFIGS = {
 
 
 # --------------------------------------------------------------------------
+# A camera on the move.  The reference renders only after the camera has moved or the scene has
+# changed (main.rs:74-78 `update_camera` -> `update_raytrace_image`): its six buttons offset the
+# camera by +-5 on one axis (main.rs:119-170).  The walk below is that and nothing else: every
+# position differs from its predecessor by one button press.
+# --------------------------------------------------------------------------
+CAMERA_MOVES = [(5., 0., 0.), (-5., 0., 0.), (0., 5., 0.), (0., -5., 0.), (0., 0., 5.), (0., 0., -5.)]
+
+
+def camera_walk(n=240, seed=0xCA3E7A, box=((-10., 10.), (0., 10.), (0., 15.))):
+    """-> n + (a few) camera positions, a closed walk from (0,0,0) by the reference's own offsets
+    inside `box` (x, y, z ranges: the demo scene stays in front of the camera; above the floor);
+    the last position is one press away from the first, so the list can be cycled."""
+    u = _splitmix64(seed)
+    pos, out = [0., 0., 0.], []
+    while len(out) < n:
+        m = CAMERA_MOVES[int(next(u) * 6) % 6]
+        q = [pos[i] + m[i] for i in range(3)]
+        if all(box[i][0] <= q[i] <= box[i][1] for i in range(3)):
+            pos = q
+            out.append(tuple(pos))
+    while pos != [0., 0., 0.]:                           # ... and home again, a press at a time
+        for i in range(3):
+            if pos[i] != 0.:
+                pos[i] -= 5. if pos[i] > 0. else -5.
+                out.append(tuple(pos))
+                break
+    return out
+
+
+# --------------------------------------------------------------------------
 # C5: seeded synthetic scene (SURVEY.md 8d).  SplitMix64, seed 0xC0FFEE.
 # --------------------------------------------------------------------------
 def _splitmix64(seed):
