@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 4u
+#define RM_ABI_VERSION 5u
 
 typedef enum rm_status {
     RM_OK = 0,
@@ -275,9 +275,13 @@ rm_status rm_render_display(rm_ctx *ctx, const rm_params *params, uint8_t *host_
  * f64 rows of the device-resident frame on demand (save_to_file, main.rs:353-357: normalize +
  * write_ppm read the f64 values): patch rows [patch_row_begin, patch_row_end) -- end 0 = all
  * whole patch rows -- of the frame the last rm_render / rm_render_rows / rm_render_display left
- * on the device, into rows[y] (as rm_render_rows).
+ * on the device, into rows[y] (as rm_render_rows).  frame_width x frame_height is the size of the
+ * FrameBuffer `rows` belongs to -- frame_height pointers to frame_width * 3 doubles each: it must be
+ * the size of the resident frame (a window that has been resized since holds another), else
+ * RM_ERR_INVALID_ARG and nothing is read or written (ABI 5; ABI 4 took no size and trusted the caller).
  */
-rm_status rm_fetch_rows(rm_ctx *ctx, double *const *rows, uint32_t patch_row_begin, uint32_t patch_row_end);
+rm_status rm_fetch_rows(rm_ctx *ctx, double *const *rows, uint32_t frame_width, uint32_t frame_height,
+                        uint32_t patch_row_begin, uint32_t patch_row_end);
 
 /* What the last rm_render / rm_render_rows / rm_fetch_rows / rm_render_display of this context
  * moved: bytes that crossed the link, 32x32 patches of the band, patches among them that were

@@ -111,7 +111,7 @@ SIGNATURES = {
     "rm_render": (C.c_int, [_VP, _P(rm_params), _P(C.c_double), _P(rm_timing)]),
     "rm_render_rows": (C.c_int, [_VP, _P(rm_params), _P(_P(C.c_double)), _P(rm_timing)]),
     "rm_render_display": (C.c_int, [_VP, _P(rm_params), _P(C.c_uint8), _P(rm_timing)]),
-    "rm_fetch_rows": (C.c_int, [_VP, _P(_P(C.c_double)), C.c_uint32, C.c_uint32]),
+    "rm_fetch_rows": (C.c_int, [_VP, _P(_P(C.c_double)), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rm_hostio_stats": (C.c_int, [_VP, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64), _P(C.c_int)]),
     "rm_render_device": (C.c_int, [_VP, _P(rm_params), _VP, _VP]),
     "rm_render_device_u8": (C.c_int, [_VP, _P(rm_params), _VP, _VP, _VP]),

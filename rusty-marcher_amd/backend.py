@@ -69,8 +69,14 @@ class Context:
                                             C.byref(t)), self.ptr)
         return t
 
-    def fetch_rows(self, rows, patch_row_begin=0, patch_row_end=0):
-        _lib.check(self.L.rm_fetch_rows(self.ptr, self.row_pointers(rows), patch_row_begin, patch_row_end), self.ptr)
+    def fetch_rows(self, rows, patch_row_begin=0, patch_row_end=0, width=None):
+        """`rows`: the FrameBuffer's rows, all of them (None for rows not to be touched): their count is its height,
+        a row's length / 3 its width (`width` where every row is None)."""
+        w = width if width is not None else next((r.size // 3 for r in rows if r is not None), 0)
+        for r in rows:
+            if r is not None and r.size != w * 3:
+                raise ValueError("fetch_rows: a row of %d doubles in a FrameBuffer %d wide" % (r.size, w))
+        _lib.check(self.L.rm_fetch_rows(self.ptr, self.row_pointers(rows), w, len(rows), patch_row_begin, patch_row_end), self.ptr)
 
     def tile_stats(self, stream=None):
         """(tiles of the last render launch, tiles the classification listed for rendering)"""

@@ -326,7 +326,7 @@ const void *rm_pick_kernel(bool fast, bool staged, bool bvh, bool cull, bool edg
 extern "C" {
 
 const char *rm_build_info(void) {
-    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi4";
+    return "rusty-marcher_amd " RM_BUILD_FLAVOR " gfx950 abi5";
 }
 
 const char *rm_last_error(const rm_ctx *ctx) {

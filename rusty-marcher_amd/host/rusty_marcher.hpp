@@ -244,9 +244,15 @@ struct FrameBuffer {
     size_t width, height;
     std::vector<std::vector<Vec3f>> buffer;   // [height] rows of [width] pixels
     // what rm_render_rows / rm_fetch_rows take: one pointer per scan line
+    // (width, height and buffer are public, as in the reference: a frame whose fields disagree is refused here -- the
+    // library writes width * 3 doubles into each of height rows)
     std::vector<double *> row_pointers() {
+        if (buffer.size() < height) throw std::runtime_error("FrameBuffer: fewer rows than its height");
         std::vector<double *> rows(height);
-        for (size_t y = 0; y < height; y++) rows[y] = reinterpret_cast<double *>(buffer[y].data());
+        for (size_t y = 0; y < height; y++) {
+            if (buffer[y].size() != width) throw std::runtime_error("FrameBuffer: a row that is not `width` pixels long");
+            rows[y] = reinterpret_cast<double *>(buffer[y].data());
+        }
         return rows;
     }
     static uint8_t quantize(double f) {                                   // framebuffer.rs:80-82
@@ -326,7 +332,8 @@ struct Renderer {
     // f64 rows of the device-resident frame on demand (save_to_file: normalize + write_ppm)
     void fetch(framebuffer::FrameBuffer &frame) {
         std::vector<double *> rows = frame.row_pointers();
-        check(rm_fetch_rows(context(), rows.data(), 0, 0), ctx_);
+        // (refused with RM_ERR_INVALID_ARG when the frame on the device is of another size: a window resized since)
+        check(rm_fetch_rows(context(), rows.data(), (uint32_t)frame.width, (uint32_t)frame.height, 0, 0), ctx_);
     }
     rm_ctx *context() { if (!ctx_) check(rm_init(0, &ctx_)); return ctx_; }
 

@@ -141,7 +141,7 @@ extern "C" {
     fn rm_render(ctx: *mut RmCtx, params: *const RmParams, host_rgb: *mut f64, timing: *mut RmTiming) -> c_int;
     fn rm_render_rows(ctx: *mut RmCtx, params: *const RmParams, rows: *const *mut f64, timing: *mut RmTiming) -> c_int;
     fn rm_render_display(ctx: *mut RmCtx, params: *const RmParams, host_rgb8: *mut u8, timing: *mut RmTiming) -> c_int;
-    fn rm_fetch_rows(ctx: *mut RmCtx, rows: *const *mut f64, patch_row_begin: u32, patch_row_end: u32) -> c_int;
+    fn rm_fetch_rows(ctx: *mut RmCtx, rows: *const *mut f64, frame_width: u32, frame_height: u32, patch_row_begin: u32, patch_row_end: u32) -> c_int;
     fn rm_hostio_stats(ctx: *mut RmCtx, bytes_copied: *mut u64, patches: *mut u64, patches_sent: *mut u64, threads: *mut c_int) -> c_int;
     fn rm_render_device(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, hip_stream: *mut c_void) -> c_int;
     fn rm_render_device_u8(ctx: *mut RmCtx, params: *const RmParams, device_rgb: *mut c_void, device_rgb8: *mut c_void, hip_stream: *mut c_void) -> c_int;
@@ -226,7 +226,18 @@ pub struct Gpu {
 /// line.  With `#[repr(C)]` on `Vec3f` (geometry.rs:4-8: three f64, x y z -- INTEGRATION.md
 /// section 3d, the fourth one-line patch) a row is `width * 3` doubles and the library fills the
 /// rows in place.
+///
+/// `buffer`, `width` and `height` are all `pub` (framebuffer.rs:6-10), so nothing but this check stands between a
+/// FrameBuffer whose fields disagree and a write beyond a row's allocation: the library writes `width * 3` doubles
+/// into each of `height` rows.  A panic here is the reference's own failure mode for such a frame (its scatter,
+/// renderer.rs:92-108, indexes out of bounds).
 fn row_pointers(frame: &mut FrameBuffer) -> Vec<*mut f64> {
+    // the cast below reads a Vec3f as three consecutive f64: true only with `#[repr(C)]`
+    const _VEC3F_IS_THREE_F64: [(); 24] = [(); ::std::mem::size_of::<Vec3f>()];
+    assert!(frame.buffer.len() >= frame.height, "FrameBuffer: {} rows for a height of {}", frame.buffer.len(), frame.height);
+    for (y, row) in frame.buffer.iter().enumerate() {
+        assert!(row.len() == frame.width, "FrameBuffer: row {} holds {} pixels for a width of {}", y, row.len(), frame.width);
+    }
     frame.buffer.iter_mut().map(|row| row.as_mut_ptr() as *mut f64).collect()
 }
 
@@ -333,7 +344,8 @@ impl Gpu {
     /// The f64 rows of the frame the last render left on the device, into `frame.buffer`.
     pub fn fetch(&mut self, frame: &mut FrameBuffer) {
         let rows = row_pointers(frame);
-        check(unsafe { rm_fetch_rows(self.ctx, rows.as_ptr(), 0, 0) }, self.ctx);
+        // (the library refuses a FrameBuffer of another size than the frame it holds: a window resized since the render)
+        check(unsafe { rm_fetch_rows(self.ctx, rows.as_ptr(), frame.width as u32, frame.height as u32, 0, 0) }, self.ctx);
     }
 }
 

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound(pkg, entry):
 
 def test_abi_version_and_build_info(pkg):
     L = pkg.lib()
-    assert L.rm_abi_version() == 4            # 3: rm_render_rows, rm_render_display, rm_fetch_rows, rm_hostio_stats, rm_tile_stats; 4: rm_launch_stats
+    assert L.rm_abi_version() == 5            # 3: rm_render_rows, rm_render_display, rm_fetch_rows, rm_hostio_stats, rm_tile_stats; 4: rm_launch_stats; 5: rm_fetch_rows takes the FrameBuffer's size
     info = L.rm_build_info().decode()
     assert "gfx950" in info
 
@@ -135,7 +135,7 @@ def test_exchange_layout_and_comm_entry_points_without_a_gpu(pkg):
     assert L.rm_buffer_write(None, None, None, 0) == E
     assert L.rm_render_rows(None, None, None, None) == E
     assert L.rm_render_display(None, None, None, None) == E
-    assert L.rm_fetch_rows(None, None, 0, 0) == E
+    assert L.rm_fetch_rows(None, None, 0, 0, 0, 0) == E
     assert L.rm_hostio_stats(None, None, None, None, None) == E
     assert L.rm_tile_stats(None, None, None, None) == E
     assert L.rm_launch_stats(None, None, None) == E

@@ -152,6 +152,32 @@ def test_negative_zero_and_nan_are_not_black(pkg, monkeypatch):
         ctx.close()
 
 
+def test_fetch_rows_refuses_a_framebuffer_of_another_size(pkg):
+    """rm_fetch_rows writes frame_width * 3 doubles into each of frame_height rows of the caller's
+    FrameBuffer -- of the frame it HOLDS.  A FrameBuffer of another size (a window resized since the render) must be
+    refused, nothing read or written (ABI 5: the call takes the FrameBuffer's size)."""
+    ctx = pkg.backend.Context(0)
+    try:
+        upload(pkg, ctx, "demo")
+        w, h = 256, 160
+        ctx.render(pkg.backend.make_params(workloads.FOV, float(h), float(w), 3), None)
+        good = make_rows(h, w, fill=3.)
+        ctx.fetch_rows(good)
+        assert (stack(good)[:h // 32 * 32] != 3.).all()
+        for hh, ww in ((h, w - 32), (h - 32, w), (h + 64, w), (h, w + 32)):
+            rows = make_rows(hh, ww, fill=4.)
+            with pytest.raises(pkg.BackendError) as e:
+                ctx.fetch_rows(rows)
+            assert e.value.status == pkg._lib.RM_ERR_INVALID_ARG and "resident frame" in str(e.value)
+            assert (stack(rows) == 4.).all()
+        ragged = make_rows(h, w, fill=4.)
+        ragged[7] = np.full(3 * (w - 1), 4.)
+        with pytest.raises(ValueError):
+            ctx.fetch_rows(ragged)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("subbands", ["1", "4", "7"])
 @pytest.mark.parametrize("cfg", [("demo", 1920, 1080, 5), ("cornell", 800, 600, 3), ("synthetic256", 512, 384, 8), ("demo", 320, 250, 0)])
 def test_display_bytes_with_a_device_resident_frame(pkg, O, monkeypatch, subbands, cfg):
