@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 while read -r line; do
   [ -z "$line" ] && continue
-  env $line python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --check "$@" 2>/tmp/ab_err.log | LINE="$line" python3 -c "
+  env $line python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-motion --check "$@" 2>/tmp/ab_err.log | LINE="$line" python3 -c "
 import json,sys,os
 t=sys.stdin.read()
 line=os.environ['LINE'].replace(os.environ.get('GRAFT_REPO_ROOT','@@')+'/rusty-marcher_amd/lib/variants/','')

@@ -149,19 +149,24 @@ struct rm_tile_lists {
     void *block = nullptr;            // mask[cap] u64
     uint64_t used = 0;
     // Dispatch order from the launch's own classification (KernelArgs::ord_*), one block per stream:
-    //   sig[2][cap] u64 | cost[2][cap] u32 | ctab[2][64] u32 | ctl[2][32] u32 | list[16][cap] u32      (cap: patches)
-    // the pairs alternate from launch to launch (a launch reads what its predecessor on the stream wrote)
+    //   cost[3][cap] | ctab[3][128] | cnt[2][RM_ORD_CNT_WORDS] | flat[2][cap] | first[2][cap] | index[2][cap] | rec[3][cap + 4096]      (u32; cap: patches)
+    // the sets take turns from launch to launch (a launch reads what its predecessor on the stream wrote, and clears what
+    // its successor will count into)
     void *order_block = nullptr;
     uint32_t order_cap = 0, order_frames = 0;
     uint64_t order_key[3] = {0, 0, 0};
-    unsigned long long *sig(uint32_t j) const { return static_cast<unsigned long long *>(order_block) + (size_t)j * order_cap; }
-    uint32_t *words() const { return reinterpret_cast<uint32_t *>(sig(2)); }
+    uint32_t *words() const { return static_cast<uint32_t *>(order_block); }
     uint32_t *cost(uint32_t j) const { return words() + (size_t)j * order_cap; }
-    uint32_t *ctab(uint32_t j) const { return words() + 2u * (size_t)order_cap + j * RM_CTAB_WORDS; }
-    uint32_t *ctl(uint32_t j) const { return words() + 2u * (size_t)order_cap + 2u * RM_CTAB_WORDS + j * RM_ORD_CTL_WORDS; }
-    uint32_t *list() const { return words() + 2u * (size_t)order_cap + 2u * RM_CTAB_WORDS + 2u * RM_ORD_CTL_WORDS; }
-    static size_t order_bytes(uint32_t cap) { return (size_t)cap * 16u + ((size_t)cap * (2u + RM_ORD_BUCKETS) + 2u * RM_CTAB_WORDS + 2u * RM_ORD_CTL_WORDS) * 4u; }
-    // sky tail: the last classifying workgroup's word in page-locked memory -- (launch seq << 32) | ordered patches with something
+    uint32_t *ctab(uint32_t j) const { return words() + 3u * (size_t)order_cap + j * RM_CTAB_WORDS; }
+    uint32_t *cnt(uint32_t j) const { return words() + 3u * (size_t)order_cap + 3u * RM_CTAB_WORDS + j * RM_ORD_CNT_WORDS; }
+    uint32_t *flat(uint32_t j) const { return cnt(2) + (size_t)j * order_cap; }
+    uint32_t *first(uint32_t j) const { return flat(2u + j); }
+    uint32_t *index(uint32_t j) const { return flat(4u + j); }
+    uint32_t *rec() const { return flat(6u); }
+    static size_t order_bytes(uint32_t cap) { return ((size_t)cap * 9u + 3u * ((size_t)cap + 4096u) + 3u * RM_CTAB_WORDS + 2u * RM_ORD_CNT_WORDS) * 4u; }
+    int static_read = -1, static_written = -1;   // the first[] / index[] pair the previous launch's first round came from / the one it wrote for a successor (-1: none)
+    uint32_t last_tag = 0;            // the tag of the order the previous launch laid out (0: none to dispatch by)
+    // sky tail: the first classifying workgroup's word in page-locked memory -- (launch seq << 32) | ordered patches with something
     // to hit --, behind it the word a wave writes when it gives up a wait that cannot fail; the launches on this stream counted, the
     // first launch of the view being rendered, the first of this geometry and scene, and that view
     unsigned long long *hint = nullptr;
@@ -227,10 +232,13 @@ struct rm_ctx {
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    bool order_late_places = true;       // RM_ORDER_LATE_PLACES=0: the classifying workgroups always write the order's places themselves (A/B knob)
+    bool order_reuse = true;             // RM_ORDER_REUSE=0: every launch dispatches by its own order, standing view or not (A/B knob)
+    bool first_round_from_order = true;  // RM_FIRST_ROUND_FROM_ORDER=0: the first round is the bottom rows by place (A/B knob)
     int first_round = -1;                // RM_FIRST_ROUND=n: the waves that neither wait for their tiles' classification nor take a place in the order (unset: what is resident at once)
     int order_keys = -1;                 // RM_ORDER_KEYS=0 by place only, 1 the previous frame's times by place only, 2 cost by content only (A/B knob; unset: times while the view stands, content once it has moved)
     uint32_t ord_tag_wrap = 0;           // RM_ORD_TAG_WRAP=n (test hook): the order's tags start afresh after n launches instead of 4,095
-    bool test_stall_order = false;       // RM_TEST_STALL_ORDER=1 (test hook): the waves wait for one classifying workgroup more than there is
+    bool test_stall_order = false;       // RM_TEST_STALL_ORDER=1 (test hook): the launch's order is never laid out
     int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
     int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
     std::vector<rm_tile_lists> tile_lists;
@@ -385,6 +393,9 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_SKY_TAIL_CAP")) ctx->sky_tail_cap = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_ORDER_KEYS")) ctx->order_keys = std::atoi(env);
     if (const char *env = std::getenv("RM_FIRST_ROUND")) ctx->first_round = std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_FIRST_ROUND_FROM_ORDER")) ctx->first_round_from_order = env[0] != '0';
+    if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = env[0] == '1';
     if (const char *env = std::getenv("RM_TILE_ORDER"))
@@ -1147,10 +1158,10 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         }
     }
     // Dispatch order from the launch's own classification, and the sky tail (KernelArgs::ord_*; rm_classify.inc place_patch /
-    // cls_finish, rm_render_kernel.inc order_entry / sky_tail_patch).  The reference renders only after the camera has moved
+    // order_slot / order_places, rm_render_kernel.inc order_entry / sky_tail_patch).  The reference renders only after the camera has moved
     // (main.rs:74-78): an order by place from earlier frames is stale exactly then (r3: demo 1080p 68.5 us standing, 78.7 with a
-    // press before every frame).  The classifying workgroups at the launch's head put every patch behind the first round into
-    // one of sixteen buckets -- by its longest tile's time in the previous frame while the view stands still, by the cost of what
+    // press before every frame).  The classifying workgroups at the launch's head give every patch behind the first round
+    // one of sixteen keys -- by its longest tile's time in the previous frame while the view stands still, by the cost of what
     // it can reach (learned per primitive from earlier frames: it moves with the picture) once it has moved, the sky last.
     // Only the order of dispatch and the launch's geometry depend on any of it: every tile of every frame is rendered in full by
     // the same code, exactly once.
@@ -1172,7 +1183,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 RM_HIP(ctx, hipMalloc(&tl->order_block, rm_tile_lists::order_bytes(n_patches)));
                 tl->order_key[0] = ~0ull;
             }
-            // (an entry of the list is taken by its tag: another geometry or scene, or the tags used up -> start afresh)
+            // (an entry of the order is taken by its tag: another geometry or scene, or the tags used up -> start afresh)
             const uint32_t tag_wrap = ctx->ord_tag_wrap ? ctx->ord_tag_wrap : (1u << RM_ORD_TAG_BITS) - 1u;
             const bool fresh = std::memcmp(tl->order_key, key, sizeof key) != 0;
             if (fresh || tl->ord_tag >= tag_wrap) {
@@ -1181,9 +1192,11 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                     std::memcpy(tl->order_key, key, sizeof key);
                     tl->order_frames = 0;
                 } else {
-                    RM_HIP(ctx, hipMemsetAsync(tl->list(), 0, (size_t)RM_ORD_BUCKETS * tl->order_cap * sizeof(uint32_t), stream));
+                    RM_HIP(ctx, hipMemsetAsync(tl->flat(0), 0, 2u * (size_t)tl->order_cap * sizeof(uint32_t), stream));
                 }
+                if (fresh) tl->static_read = tl->static_written = -1;
                 tl->ord_tag = 0;
+                tl->last_tag = 0;
             }
             if (!tl->hint) {
                 RM_HIP(ctx, hipHostMalloc((void **)&tl->hint, 2u * sizeof(unsigned long long), hipHostMallocDefault));
@@ -1200,27 +1213,58 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 tl->view_seq0 = seq;
             }
             const bool timed = n_patches <= ctx->patch_order_max;             // (larger launches are many rounds deep: by place, for the sky tail alone)
-            a.ord_ctl = tl->ctl(f & 1u);
-            a.ord_ctl_next = tl->ctl((f + 1u) & 1u);
-            a.ord_list = tl->list();
+            // the classifying workgroups wait for each other: they must all be resident, whatever the kernel's occupancy --
+            // at most 1,024 of them, each taking as many groups of four patches, one after the other, as that needs
+            grid.x -= a.cls_blocks;
+            const uint32_t groups4 = (n_patches + 3u) / 4u;
+            a.cls_iters = (groups4 + RM_ORD_MAX_CLS - 1u) / RM_ORD_MAX_CLS;
+            a.cls_blocks = (groups4 + a.cls_iters - 1u) / a.cls_iters;
+            a.ord_cnt = tl->cnt(f & 1u);
+            a.ord_cnt_next = tl->cnt((f + 1u) & 1u);
+            // While the view stands still a launch dispatches by the order its predecessor laid out -- same view, same
+            // classification, the same first round: nothing to wait for -- and lays out the next launch's, from tile times a
+            // frame fresher.  A view that has moved dispatches by its own order (the waves behind the first round wait for it).
+            // (from the view's THIRD launch on: its second still dispatches by its own order, with a first round taken from the
+            // first's -- this view's dearest patches, which the launches after it keep)
+            const bool reuse = ctx->order_reuse && f >= 2u && seq >= tl->view_seq0 + 2u && tl->last_tag != 0u;
+            a.ord_flat = tl->flat(f & 1u);
             a.ord_cap = tl->order_cap;
             a.ord_tag = ++tl->ord_tag;
-            a.sig_cur = tl->sig(f & 1u);
-            a.sig_prev = tl->sig((f + 1u) & 1u);
-            a.patch_cost = timed ? tl->cost(f & 1u) : nullptr;
-            a.cost_prev = timed ? tl->cost((f + 1u) & 1u) : nullptr;
-            a.ctab = tl->ctab((f + 1u) & 1u);
-            a.ctab_next = timed ? tl->ctab(f & 1u) : nullptr;
+            a.ord_read = reuse ? tl->flat((f + 1u) & 1u) : a.ord_flat;
+            a.ord_read_tag = reuse ? tl->last_tag : a.ord_tag;
+            tl->last_tag = a.ord_tag;
+            a.ord_rec = reuse && ctx->order_late_places ? tl->rec() : nullptr;
+            a.patch_cost = timed ? tl->cost(f % 3u) : nullptr;
+            a.cost_prev = timed ? tl->cost((f + 2u) % 3u) : nullptr;
+            a.cost_zero = timed ? tl->cost((f + 1u) % 3u) : nullptr;
+            a.ctab = tl->ctab((f + 2u) % 3u);
+            a.ctab_cur = timed && ctx->order_keys != 1 ? tl->ctab(f % 3u) : nullptr;
+            a.ctab_zero = tl->ctab((f + 1u) % 3u);
+            // The first round: the first places of the order the previous launch laid out (its classifying workgroups wrote them
+            // down) -- unless this launch dispatches by that very order: then it keeps its predecessor's first round, which that
+            // order leaves out.  Every launch writes the first places of the order it lays out for whoever comes next.
+            if (ctx->first_round_from_order && a.n_static / 16u <= n_dyn) {
+                const int read = reuse ? tl->static_read : tl->static_written;
+                const uint32_t write = read == 0 ? 1u : 0u;
+                a.static_list = read >= 0 ? tl->first((uint32_t)read) : nullptr;
+                a.dyn_index = read >= 0 ? tl->index((uint32_t)read) : nullptr;
+                a.static_next = tl->first(write);
+                a.dyn_index_next = tl->index(write);
+                tl->static_read = read;
+                tl->static_written = (int)write;
+            } else {
+                tl->static_read = tl->static_written = -1;
+            }
             // what the patches are ordered by: the previous frame's times by place while the view is the one that frame had; else
             // the cost of what a patch can reach, once a table exists (written by the launch before from the launch before that)
             a.key_mode = !timed || f == 0u || ctx->order_keys == 0 ? RM_KEY_PLACE
                        : (seq > tl->view_seq0 && ctx->order_keys != 2) ? RM_KEY_COST
-                       : (f >= 2u && a.mask_exact && ctx->order_keys != 1) ? RM_KEY_CONTENT : RM_KEY_PLACE;
+                       : (a.mask_exact && a.mask_tag && ctx->order_keys != 1) ? RM_KEY_CONTENT : RM_KEY_PLACE;
             a.ord_hint = tl->hint;
             a.err_word = tl->hint + 1;
             a.launch_seq = seq;
-            a.cls_tally = a.cls_blocks + (ctx->test_stall_order ? 1u : 0u);       // (test hook: a tally that never completes)
-            // Sky tail.  The last classifying workgroup of every launch tells the host how many of the ordered patches had
+            a.test_stall = ctx->test_stall_order ? 1u : 0u;                     // (test hook: an order that is never laid out)
+            // Sky tail.  The first classifying workgroup of every launch tells the host how many of the ordered patches had
             // something to hit (page-locked memory, read here without a wait).  The places behind them -- the sky -- get one wave
             // each instead of sixteen (the dispatcher takes ~0.7 ns per wave that finds out that its tile is sky: half of a
             // Cornell launch).  From a frame of THIS view the count is exact; from an earlier view it is a guess, and the places
@@ -1235,16 +1279,18 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                     const unsigned long long h = *(volatile unsigned long long *)tl->hint;
                     const uint32_t h_seq = (uint32_t)(h >> 32), n_lit = (uint32_t)h;
                     const bool valid = h_seq >= tl->key_seq0 && h_seq < seq && h != 0ull && n_lit <= n_dyn;
-                    guess = h_seq < tl->view_seq0;
+                    guess = h_seq < tl->view_seq0 + 1u;                 // (the view's first launch may have had another first round)
                     if (valid && (!guess || ctx->sky_tail_motion)) tail = n_dyn - n_lit;
                     if (tail < 8u) tail = 0u;
                 }
                 // (room to hand on: a press of the reference's buttons turns a few hundred of a 1080p frame's 1,980 patches)
-                if (tail && guess) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : std::max(512u, n_patches / 16u));
+                // (a count from this very view is exact -- which patches went first does not change it -- but a place too many in the
+                // tail with nobody to hand it to costs sixteen tiles one after the other: a little room all the same)
+                if (tail) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : guess ? std::max(512u, n_patches / 16u) : 32u);
             }
             a.tail_patches = tail;
             a.ov_cap = cap;
-            grid.x = a.cls_blocks + a.n_static + 16u * (n_dyn - tail) + tail + 16u * cap;
+            grid.x = a.cls_blocks + a.n_static + 16u * (n_dyn - tail) + tail + 16u * cap + (a.ord_rec ? a.cls_blocks : 0u);
             // (dealt out evenly among the tile waves behind the launch's first round: rm_render_kernel.inc)
             const uint64_t behind = 16ull * (n_dyn - tail);
             a.tail_q = (tail && behind) ? (uint32_t)((((uint64_t)tail << 32) + behind + tail - 1u) / (behind + tail)) : 0u;
@@ -1265,22 +1311,36 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     RM_HIP(ctx, hipLaunchKernel(fn, grid, block, args, lds, stream));
     ctx->last_launch_grid = grid.x;
     ctx->last_launch_tail = a.tail_patches;
-    if (a.ord_ctl && std::getenv("RM_DEBUG_TAIL")) {                    // (diagnostic: waits for the launch)
-        uint32_t c[RM_ORD_CTL_WORDS] = {};
+    if (a.ord_cnt && std::getenv("RM_DEBUG_TAIL")) {                    // (diagnostic: waits for the launch)
+        uint32_t c[RM_ORD_BUCKETS] = {}, raw[RM_ORD_ARRIVE] = {};
         RM_HIP(ctx, hipStreamSynchronize(stream));
-        RM_HIP(ctx, hipMemcpy(c, a.ord_ctl, sizeof c, hipMemcpyDeviceToHost));
+        RM_HIP(ctx, hipMemcpy(raw, a.ord_cnt, sizeof raw, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) c[b] = raw[b * RM_ORD_LINE];
         uint32_t lit = 0;
         for (uint32_t b = 0; b < RM_ORD_SKY; b++) lit += c[b];
-        std::fprintf(stderr, "[rm_order] launch %u keys %u: first round %u waves, %u + %u sky places; tail %u, room to hand on %u, handed on %u; buckets", a.launch_seq, a.key_mode,
-                     a.n_static, lit, c[RM_ORD_SKY], a.tail_patches, a.ov_cap, a.tail_patches > c[RM_ORD_SKY] ? std::min(a.ov_cap, a.tail_patches - c[RM_ORD_SKY]) : 0u);
+        std::fprintf(stderr, "[rm_order] launch %u keys %u: %u classifying workgroups x %u, first round %u waves, %u + %u sky places; tail %u, room to hand on %u, handed on %u; buckets", a.launch_seq, a.key_mode,
+                     a.cls_blocks, a.cls_iters, a.n_static, lit, c[RM_ORD_SKY], a.tail_patches, a.ov_cap, a.tail_patches > c[RM_ORD_SKY] ? std::min(a.ov_cap, a.tail_patches - c[RM_ORD_SKY]) : 0u);
         for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) std::fprintf(stderr, " %u", c[b]);
-        std::fprintf(stderr, "\n");
+        // (the order this launch laid out: every place taken, by a patch of its own)
+        const uint32_t n_pat = a.n_tiles / 16u, n_dyn_ = n_pat - a.n_static / 16u;
+        std::vector<uint32_t> fl(n_dyn_);
+        RM_HIP(ctx, hipMemcpy(fl.data(), a.ord_flat, n_dyn_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> seen(n_pat, 0);
+        uint32_t untagged = 0, twice = 0, bad = 0;
+        for (uint32_t v : fl) {
+            if ((v >> RM_ORD_TAG_SHIFT) != a.ord_tag) { untagged++; continue; }
+            const uint32_t pch = v & (RM_ORD_SKY_BIT - 1u);
+            if (pch >= n_pat) { bad++; continue; }
+            twice += seen[pch]; seen[pch] = 1;
+        }
+        std::fprintf(stderr, " | order laid out: %u places, %u without the tag, %u patches twice, %u out of range; dispatched by %s order; places written %s\n", n_dyn_, untagged, twice, bad,
+                     a.ord_read == a.ord_flat ? "its own" : "its predecessor's", a.ord_rec ? "at the grid's end" : "by the classifying workgroups");
     }
     if (fb) fb->cur = (fb->cur + 1) % 3;
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
     RM_HIP(ctx, hipStreamSynchronize(stream));
     if (const char *path = std::getenv("RM_DEBUG_STAMPS")) {
-        std::fprintf(stderr, "stamps: grid %u cls_blocks %u n_static %u n_tiles %u tail_patches %u tail_q %u ov_cap %u key_mode %u\n", grid.x, a.cls_blocks, a.ord_ctl ? a.n_static : 0u, a.n_tiles, a.tail_patches, a.tail_q, a.ov_cap, a.key_mode);
+        std::fprintf(stderr, "stamps: grid %u cls_blocks %u n_static %u n_tiles %u tail_patches %u tail_q %u ov_cap %u key_mode %u\n", grid.x, a.cls_blocks, a.ord_cnt ? a.n_static : 0u, a.n_tiles, a.tail_patches, a.tail_q, a.ov_cap, a.key_mode);
         std::vector<unsigned long long> h(n_waves * 4);
         RM_HIP(ctx, hipMemcpy(h.data(), d_stamps, n_waves * 32, hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }

@@ -12,10 +12,20 @@
 // dispatch order built at the launch's head (KernelArgs::ord_*): sixteen buckets, the last one the sky
 #define RM_ORD_BUCKETS 16u
 #define RM_ORD_SKY 15u
-#define RM_ORD_CTL_WORDS 32u            /* [0..15] counts, [16] tally */
-#define RM_ORD_TAG_BITS 12u
-#define RM_ORD_PATCH_BITS 20u
-#define RM_CTAB_WORDS 64u
+#define RM_ORD_MAX_CLS 1024u            /* classifying workgroups of a launch with an order: all resident, whatever the kernel's occupancy */
+/* the launch's counters, each in a 128-byte line of its own (waves that add to or ask for one word must not queue behind those of
+   another): [b] patches in bucket b | [16 + g] classifying workgroups of the g-th 32 that have arrived | [48] groups complete | [49] go */
+#define RM_ORD_LINE 32u
+#define RM_ORD_ARRIVE (RM_ORD_BUCKETS * RM_ORD_LINE)
+#define RM_ORD_GROUPS (RM_ORD_ARRIVE + (RM_ORD_MAX_CLS / 32u) * RM_ORD_LINE)
+#define RM_ORD_GO (RM_ORD_GROUPS + RM_ORD_LINE)
+#define RM_ORD_CNT_WORDS (RM_ORD_GO + RM_ORD_LINE)
+#define RM_ORD_STATIC_BIT 0x80000000u
+#define RM_ORD_PATCH_BITS 20u           /* an entry: patch | sky << 20 | tag << 21 */
+#define RM_ORD_SKY_BIT (1u << RM_ORD_PATCH_BITS)
+#define RM_ORD_TAG_SHIFT (RM_ORD_PATCH_BITS + 1u)
+#define RM_ORD_TAG_BITS 11u
+#define RM_CTAB_WORDS 128u             /* sums | counts */
 enum { RM_KEY_PLACE = 0, RM_KEY_COST = 1, RM_KEY_CONTENT = 2 };
 
 // waves per SIMD the integer-power kernels are compiled for (register budget 512 / this)
@@ -90,28 +100,44 @@ struct KernelArgs {
     uint32_t mask_tag;
     uint32_t cls_blocks;
     uint32_t cls_prims;
-    // Dispatch order from THIS launch's classification (rm_classify.inc `place_patch`, rm_render_kernel.inc `order_entry`).
+    // Dispatch order from THIS launch's classification (rm_classify.inc `order_patches`, rm_render_kernel.inc `order_entry`).
     // The reference renders only after the camera has moved (main.rs:74-78), so an order kept from earlier frames BY PLACE is
     // stale exactly when it is needed.  Instead the classifying workgroups at the launch's head, which know what each patch's
     // primary rays can reach, put every patch behind the launch's first round into one of sixteen buckets -- by what the
-    // patch's longest tile cost in the previous frame while the view stands still, else by what patches reaching the same
-    // primitives cost in earlier frames (cost by content: it moves with the picture), the sky last -- with one atomic each;
-    // a render wave behind the first round takes the k-th patch of the buckets laid end to end once every classifying
-    // workgroup has said it is done (ord_ctl[16]).  The first round -- the waves resident at once -- renders the bottom rows
-    // by place and waits for nobody.  Only the order of dispatch depends on any of it.  ord_ctl == NULL: off.
-    uint32_t *ord_ctl;                       // this launch: [0..15] patches per bucket, [16] classifying workgroups done
-    uint32_t *ord_ctl_next;                  // the next launch's block: cleared by the last classifying workgroup of this one
-    uint32_t *ord_list;                      // RM_ORD_BUCKETS x ord_cap entries: (ord_tag << 20) | patch
-    uint32_t ord_cap;                        // entries per bucket (the patches behind the first round)
-    uint32_t ord_tag;                        // 1..4095: an entry is there once it carries this launch's tag
-    uint32_t n_static;                       // waves of the first round (a multiple of 16): the bottom rows by place
+    // patch's longest tile cost in the previous frame while the view stands still, else by what tiles reaching the same
+    // primitives cost in the previous frame (cost by content: it moves with the picture), the sky last: one atomic per wave
+    // and bucket gives its patches their slots.  The classifying workgroups -- at most 1,024, all resident -- then wait for
+    // each other (the last of each 32 to arrive tells the launch, the last of those says go), read the sixteen totals and write their own patches' places into
+    // THE ORDER (ord_flat); a render wave behind the first round takes the k-th entry of that: one load, the entry says
+    // itself when it is there.  Nothing serial anywhere.  The first round -- the waves resident at once -- renders the first
+    // places of the PREVIOUS launch's order (its dearest patches; the bottom rows where there is none) and waits for nobody.
+    // Only the order of dispatch depends on any of it.  ord_cnt == NULL: off.
+    uint32_t *ord_cnt;                       // this launch's counters (RM_ORD_CNT_WORDS: patches per bucket, classifying workgroups arrived, go)
+    uint32_t *ord_cnt_next;                  // the next launch's block: cleared by this launch's first classifying workgroup
+    uint32_t *ord_flat;                      // ord_cap entries, the order this launch lays out: patch | sky << 20 | ord_tag << 21
+    // ... and the order it DISPATCHES by: its own (a view that has moved: the waves behind the first round wait for it, 10-20 us
+    // into the launch) -- or, while the view stands still, the one the previous launch laid out (same view, same classification,
+    // the same first round: nothing to wait for), this launch's then being the next one's, from tile times a frame fresher
+    const uint32_t *ord_read;
+    uint32_t ord_read_tag;
+    // (... in which case nobody waits for the order being laid out: the classifying workgroups leave their patches' slots in
+    // memory and go -- 495 wave slots held for the slowest of them are 3 us of a Cornell launch --, and as many workgroups
+    // at the grid's very end, long after, write the places)
+    uint32_t *ord_rec;                       // 3 words per patch group slot: patch, bucket << 24 | slot, dyn_index's word (NULL: the classifying workgroups write the places themselves)
+    uint32_t ord_cap;                        // entries (the patches behind the first round, at most)
+    uint32_t ord_tag;                        // 1..2047: an entry is there once it carries this launch's tag
+    uint32_t cls_iters;                      // groups of four patches a classifying workgroup takes, one after the other (so that they are at most 1,024)
+    const uint32_t *static_list;             // n_static / 16 patches: the first round (NULL: the bottom rows by place)
+    const uint32_t *dyn_index;               // per patch: bit 31 -- a patch of the first round, its index there below (NULL: the bottom rows)
+    uint32_t *static_next, *dyn_index_next;  // ... for the next launch: the first places of this launch's order
+    uint32_t n_static;                       // waves of the first round (a multiple of 16)
     uint32_t key_mode;                       // RM_KEY_PLACE / RM_KEY_COST / RM_KEY_CONTENT
     uint32_t *patch_cost;                    // this launch's waves: their tile's time -> max per patch (100 MHz ticks); NULL: tiles are not timed
-    uint32_t *cost_prev;                     // the previous launch's (same geometry, same scene); cleared for the next launch by this one's last classifying workgroup
-    unsigned long long *sig_cur;             // per patch: the primitives its tiles' primary rays can reach (this launch writes)
-    const unsigned long long *sig_prev;      // ... of the previous launch
-    const uint32_t *ctab;                    // cost by content: [pid] mean cost of the patches that could reach the primitive (0: not seen), from the launch before
-    uint32_t *ctab_next;                     // ... written by this launch's last classifying workgroup from (sig_prev, cost_prev)
+    const uint32_t *cost_prev;               // the previous launch's (same geometry, same scene)
+    uint32_t *cost_zero;                     // the next launch's: cleared by this launch's classifying workgroups, patch by patch
+    const uint32_t *ctab;                    // cost by content, the previous launch's: [pid] sum of the times (64-tick units) of the tiles that could reach the primitive, [64 + pid] how many
+    uint32_t *ctab_cur;                      // this launch's waves add theirs (one tile in sixteen)
+    uint32_t *ctab_zero;                     // the next launch's: cleared by this launch's first classifying workgroup
     // Sky tail: the last tail_patches places of the order get ONE wave each instead of sixteen -- sized by the host from a HINT
     // (how many patches the previous frames found nothing to hit in: ord_hint, page-locked, read without a wait).  Such a wave
     // finds its place's bucket: sky -> 24 KB of zeros.  Where the hint was a guess (the view has moved) and more patches have
@@ -124,7 +150,7 @@ struct KernelArgs {
     unsigned long long *ord_hint;            // (launch_seq << 32) | patches behind the first round with something to hit
     unsigned long long *err_word;            // page-locked: non-zero once a wave of a launch on this stream gave up a wait that cannot fail (the frame is void)
     uint32_t launch_seq;
-    uint32_t cls_tally;                      // classifying workgroups the waves wait for (= cls_blocks; a test hook overstates it)
+    uint32_t test_stall;                     // test hook: the order is never laid out (the waves behind the first round give up)
 };
 
 // What the classification launch gets besides the render launch's own arguments.

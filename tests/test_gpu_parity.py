@@ -903,8 +903,8 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
 def test_a_wait_that_is_given_up_voids_the_frame_and_says_so(pkg, monkeypatch):
     """The one wait of a render launch that has no fallback: a wave behind the first round needs its place in the
     dispatch order, which is there once every classifying workgroup of the launch has said it is done -- they are the
-    launch's first workgroups and take microseconds.  A test hook makes the waves wait for one workgroup more than
-    there is: each gives up after 10 ms, renders nothing and says so in page-locked memory.  The asynchronous launch
+    launch's first workgroups and take microseconds.  A test hook keeps the launch's last classifying workgroup from laying
+    the order out: each wave gives up after 10 ms, renders nothing and says so in page-locked memory.  The asynchronous launch
     has returned by then; the NEXT call on the stream must report the void frame (once), the synchronous calls report
     their own, and the context must come down cleanly."""
     import torch
