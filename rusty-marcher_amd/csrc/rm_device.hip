@@ -149,7 +149,7 @@ struct rm_tile_lists {
     void *block = nullptr;            // mask[cap] u64
     uint64_t used = 0;
     // Dispatch order from the launch's own classification (KernelArgs::ord_*), one block per stream:
-    //   cost[3][cap] | ctab[3][128] | cnt[2][RM_ORD_CNT_WORDS] | flat[2][cap] | first[2][cap] | index[2][cap] | rec[3][cap + 4096]      (u32; cap: patches)
+    //   cost[3][cap] | ctab[3][128] | cnt[2][RM_ORD_CNT_WORDS] | flat[2][cap] | first[2][cap] | index[2][cap] | inv[2][cap] | rec[3][cap + 4096] | done[2]      (u32; cap: patches)
     // the sets take turns from launch to launch (a launch reads what its predecessor on the stream wrote, and clears what
     // its successor will count into)
     void *order_block = nullptr;
@@ -162,8 +162,11 @@ struct rm_tile_lists {
     uint32_t *flat(uint32_t j) const { return cnt(2) + (size_t)j * order_cap; }
     uint32_t *first(uint32_t j) const { return flat(2u + j); }
     uint32_t *index(uint32_t j) const { return flat(4u + j); }
-    uint32_t *rec() const { return flat(6u); }
-    static size_t order_bytes(uint32_t cap) { return ((size_t)cap * 9u + 3u * ((size_t)cap + 4096u) + 3u * RM_CTAB_WORDS + 2u * RM_ORD_CNT_WORDS) * 4u; }
+    uint32_t *inv(uint32_t j) const { return flat(6u + j); }
+    uint32_t *rec() const { return flat(8u); }
+    uint32_t *done() const { return rec() + 3u * ((size_t)order_cap + 4096u); }
+    uint32_t list_tag[2] = {0, 0};    // the tag of the launch that was to write first[] / index[] / inv[] of that number
+    static size_t order_bytes(uint32_t cap) { return ((size_t)cap * 11u + 64u + 3u * ((size_t)cap + 4096u) + 3u * RM_CTAB_WORDS + 2u * RM_ORD_CNT_WORDS) * 4u; }
     int static_read = -1, static_written = -1;   // the first[] / index[] pair the previous launch's first round came from / the one it wrote for a successor (-1: none)
     uint32_t last_tag = 0;            // the tag of the order the previous launch laid out (0: none to dispatch by)
     // sky tail: the first classifying workgroup's word in page-locked memory -- (launch seq << 32) | ordered patches with something
@@ -238,7 +241,7 @@ struct rm_ctx {
     int first_round = -1;                // RM_FIRST_ROUND=n: the waves that neither wait for their tiles' classification nor take a place in the order (unset: what is resident at once)
     int order_keys = -1;                 // RM_ORDER_KEYS=0 by place only, 1 the previous frame's times by place only, 2 cost by content only (A/B knob; unset: times while the view stands, content once it has moved)
     uint32_t ord_tag_wrap = 0;           // RM_ORD_TAG_WRAP=n (test hook): the order's tags start afresh after n launches instead of 4,095
-    bool test_stall_order = false;       // RM_TEST_STALL_ORDER=1 (test hook): the launch's order is never laid out
+    int test_stall_order = 0;            // RM_TEST_STALL_ORDER (test hook) = 1: the launch's order is never laid out (the frame is void); = 2: its classifying workgroups never say they have arrived (the order of last resort)
     int sky_tail_force = -1;             // RM_SKY_TAIL_FORCE=n (test hook): the last n patches of the order are taken for sky, whatever the hint says
     int patch_order_mode = -1;           // RM_PATCH_ORDER=0 never, 1 whenever possible; unset: launches of RM_CLASSIFY_MIN_TILES tiles and more
     std::vector<rm_tile_lists> tile_lists;
@@ -397,7 +400,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
-    if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = env[0] == '1';
+    if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = std::atoi(env);
     if (const char *env = std::getenv("RM_TILE_ORDER"))
         ctx->tile_order = !std::strcmp(env, "reverse") ? TILE_ORDER_REVERSE
                         : !std::strcmp(env, "hash") ? TILE_ORDER_HASH : TILE_ORDER_NATURAL;
@@ -1194,7 +1197,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 } else {
                     RM_HIP(ctx, hipMemsetAsync(tl->flat(0), 0, 2u * (size_t)tl->order_cap * sizeof(uint32_t), stream));
                 }
-                if (fresh) tl->static_read = tl->static_written = -1;
+                if (fresh) { tl->static_read = tl->static_written = -1; tl->list_tag[0] = tl->list_tag[1] = 0u; }
                 tl->ord_tag = 0;
                 tl->last_tag = 0;
             }
@@ -1248,8 +1251,14 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 const uint32_t write = read == 0 ? 1u : 0u;
                 a.static_list = read >= 0 ? tl->first((uint32_t)read) : nullptr;
                 a.dyn_index = read >= 0 ? tl->index((uint32_t)read) : nullptr;
+                a.dyn_inv = read >= 0 ? tl->inv((uint32_t)read) : nullptr;
+                a.lists_done = read >= 0 ? tl->done() + read : nullptr;
+                a.lists_tag = read >= 0 ? tl->list_tag[read] : 0u;
                 a.static_next = tl->first(write);
                 a.dyn_index_next = tl->index(write);
+                a.dyn_inv_next = tl->inv(write);
+                a.lists_done_next = tl->done() + write;
+                tl->list_tag[write] = a.ord_tag;
                 tl->static_read = read;
                 tl->static_written = (int)write;
             } else {
@@ -1263,7 +1272,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             a.ord_hint = tl->hint;
             a.err_word = tl->hint + 1;
             a.launch_seq = seq;
-            a.test_stall = ctx->test_stall_order ? 1u : 0u;                     // (test hook: an order that is never laid out)
+            a.test_stall = (uint32_t)ctx->test_stall_order;                     // (test hooks)
             // Sky tail.  The first classifying workgroup of every launch tells the host how many of the ordered patches had
             // something to hit (page-locked memory, read here without a wait).  The places behind them -- the sky -- get one wave
             // each instead of sixteen (the dispatcher takes ~0.7 ns per wave that finds out that its tile is sky: half of a

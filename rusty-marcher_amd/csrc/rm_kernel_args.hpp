@@ -21,6 +21,10 @@
 #define RM_ORD_GO (RM_ORD_GROUPS + RM_ORD_LINE)
 #define RM_ORD_CNT_WORDS (RM_ORD_GO + RM_ORD_LINE)
 #define RM_ORD_STATIC_BIT 0x80000000u
+/* the launch's decision word (RM_ORD_GO): 0 undecided | its tag: every classifying workgroup has arrived, the places are being written |
+   tag + this bit: a wave gave up waiting before that -- nobody writes places, every wave takes its patch from the index instead */
+#define RM_ORD_FALLBACK_BIT 0x80000000u
+#define RM_ORD_PATIENCE 4096u           /* polls (~1 us each) before a waiting wave asks for the order of last resort */
 #define RM_ORD_PATCH_BITS 20u           /* an entry: patch | sky << 20 | tag << 21 */
 #define RM_ORD_SKY_BIT (1u << RM_ORD_PATCH_BITS)
 #define RM_ORD_TAG_SHIFT (RM_ORD_PATCH_BITS + 1u)
@@ -129,7 +133,13 @@ struct KernelArgs {
     uint32_t cls_iters;                      // groups of four patches a classifying workgroup takes, one after the other (so that they are at most 1,024)
     const uint32_t *static_list;             // n_static / 16 patches: the first round (NULL: the bottom rows by place)
     const uint32_t *dyn_index;               // per patch: bit 31 -- a patch of the first round, its index there below (NULL: the bottom rows)
-    uint32_t *static_next, *dyn_index_next;  // ... for the next launch: the first places of this launch's order
+    const uint32_t *dyn_inv;                 // the other way round: the patch at place r of the index (NULL: bottom-up) -- the order of last resort
+    uint32_t *static_next, *dyn_index_next, *dyn_inv_next;   // ... for the next launch: the first places of this launch's order
+    // (a launch that fell back on the order of last resort writes none of the three: whoever reads them checks that the launch
+    // that was to write them did -- its tag in lists_done -- and goes by the bottom rows otherwise)
+    const uint32_t *lists_done;
+    uint32_t lists_tag;
+    uint32_t *lists_done_next;
     uint32_t n_static;                       // waves of the first round (a multiple of 16)
     uint32_t key_mode;                       // RM_KEY_PLACE / RM_KEY_COST / RM_KEY_CONTENT
     uint32_t *patch_cost;                    // this launch's waves: their tile's time -> max per patch (100 MHz ticks); NULL: tiles are not timed

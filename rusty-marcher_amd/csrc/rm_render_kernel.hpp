@@ -41,6 +41,13 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)uniform_u32((uint32_t)(v >> 32)) << 32) | uniform_u32((uint32_t)v);
 }
 
+// The first round, the index and its inverse a launch came with (KernelArgs::static_list / dyn_index / dyn_inv) are there only if the
+// launch that was to write them laid out an order at all (it may have fallen back on the order of last resort): every wave of
+// this launch reads the same word of a launch that is over, so all agree.
+__device__ __forceinline__ bool lists_ok(const KernelArgs &a) {
+    return a.static_list && a.lists_done && uniform_u32(*a.lists_done) == a.lists_tag;
+}
+
 extern __shared__ double rm_lds[];
 
 // Every workgroup keeps its own copy of the scene in LDS; all later reads are

@@ -941,6 +941,52 @@ def test_a_wait_that_is_given_up_voids_the_frame_and_says_so(pkg, monkeypatch):
         c.close()
 
 
+def test_a_wave_out_of_patience_gets_the_order_of_last_resort(pkg, monkeypatch):
+    """Where a launch dispatches by its own order, the waves behind the first round wait for the classifying workgroups -- which
+    on a card shared with another process may be kept off it for as long as that takes.  A wave that runs out of patience
+    turns the launch's decision word to "the order of last resort" (unless the workgroups got there first: compare and swap):
+    then nobody writes places and EVERY wave takes its patch from the index the launch came with -- slower, and correct.  A test
+    hook keeps the classifying workgroups of such launches from ever arriving: every frame of a sequence -- the view moving,
+    standing (launches that dispatch by the order of a predecessor that never laid one out), a sky tail whose hint is wrong --
+    must equal the frame of a context without any of it, in buffers pre-filled with a sentinel, and no frame may be void."""
+    import torch
+    monkeypatch.setenv("RM_PATCH_ORDER", "0")
+    plain = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_PATCH_ORDER", "1")
+    monkeypatch.setenv("RM_TILE_CLASSIFY", "1")
+    monkeypatch.setenv("RM_FIRST_ROUND", "512")
+    monkeypatch.setenv("RM_TEST_STALL_ORDER", "2")
+    stalled = pkg.backend.Context(0)
+    monkeypatch.setenv("RM_SKY_TAIL_FORCE", "60")
+    stalled_wrong_tail = pkg.backend.Context(0)
+    for v in ("RM_PATCH_ORDER", "RM_TILE_CLASSIFY", "RM_FIRST_ROUND", "RM_TEST_STALL_ORDER", "RM_SKY_TAIL_FORCE"):
+        monkeypatch.delenv(v)
+    demo = pkg.Scene.create_default()
+    seq = [(0., 0., 0.)] * 4 + [(5., 0., 0.), (5., 0., 5.), (5., 0., 5.), (5., 0., 5.), (5., 0., 5.), (0., 5., 5.)]
+    try:
+        w, h = 800, 608
+        p = pkg.backend.make_params(workloads.FOV, float(h), float(w), 5)
+        p.flags = _FLAGS["value"]
+        for k, cam in enumerate(seq):
+            demo.camera = pkg.Vec3f(*cam)
+            outs = []
+            for c in (plain, stalled, stalled_wrong_tail):
+                c.upload(demo.flatten())
+                f64 = torch.full((h, w, 3), -1., dtype=torch.float64, device="cuda:0")
+                u8 = torch.full((h, w, 3), 201, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                c.render_device_u8(p, f64.data_ptr(), u8.data_ptr())      # (raises if an earlier frame was void)
+                torch.cuda.synchronize()
+                outs.append((f64.cpu().numpy(), u8.cpu().numpy()))
+            for j in (1, 2):
+                assert outs[0][0].tobytes() == outs[j][0].tobytes(), "frame %d: f64 differs under the order of last resort (%d)" % (k, j)
+                assert np.array_equal(outs[0][1], outs[j][1]), "frame %d: display bytes differ (%d)" % (k, j)
+            assert not (outs[1][0][:h // 32 * 32] == -1.).any()
+    finally:
+        for c in (plain, stalled, stalled_wrong_tail):
+            c.close()
+
+
 def test_three_hundred_frames_of_a_camera_on_the_move(pkg, O, monkeypatch):
     """300 launches of one geometry on one stream, the camera a press further before each (workloads.camera_walk: the
     reference's own offsets): the tags of the tile masks (8 bits) and of the dispatch order (made to start afresh every
