@@ -50,16 +50,20 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PIXEL = 24            # 3 x f64 written per pixel (framebuffer.rs Vec3f), SURVEY.md 8d
 FEEDBACK_NOTE = ("frame-to-frame feedback: the tiles that took longest in the previous frame on the stream are dispatched "
                  "first (RM_FEEDBACK=0 switches it off); every tile of every frame is rendered in full")
-CLASSIFY_NOTE = ("a launch of 16 lanes per 32x32 patch in front of the render launch tests the cone of every tile's primary rays "
-                 "against the primitives' bounds (RM_TILE_CLASSIFY=0 switches it off): tiles nothing can be hit in get a wave "
-                 "that stores the primary-miss value and leaves; every other pixel is traced in full; kernel_ms and ms_per_step "
-                 "include that launch")
-ORDER_NOTE = ("patch order: the 32x32 patches whose longest tile took longest in the previous frames on the stream are dispatched "
-              "first (RM_PATCH_ORDER=0 switches it off); sky tail: while the view is the one those frames had (this bench: always), "
-              "patches their classification found nothing to hit in get one wave instead of sixteen -- it looks at THIS launch's "
-              "classification of its patch, stores the primary-miss value where that still says sky and renders the patch itself "
-              "where it does not (RM_SKY_TAIL=0 switches it off); only the order and the geometry of the launch are carried from frame to "
-              "frame: every frame classifies every patch and every pixel with something to hit is traced in full")
+CLASSIFY_NOTE = ("the first workgroups of the render launch itself (scenes of up to 56 primitives; a launch of its own in front of it for "
+                 "larger scenes and for launches that carry the tile-level feedback) test the cone of every tile's primary rays against the "
+                 "primitives' bounds, 16 lanes per 32x32 patch (RM_TILE_CLASSIFY=0 switches it off): tiles nothing can be hit in get a wave "
+                 "that stores the primary-miss value and leaves; every other pixel is traced in full; kernel_ms and ms_per_step include it")
+ORDER_NOTE = ("dispatch order from the launch's own classification: its classifying workgroups put every 32x32 patch behind the first round "
+              "into one of sixteen buckets -- by the patch's longest tile in the previous frame while the view stands still (such a launch "
+              "dispatches by the order its predecessor laid out and lays out its successor's: nothing waits), by what tiles reaching the same "
+              "primitives cost in the previous frame once the camera has moved (the waves behind the first round then wait for the order, "
+              "10-20 us into the launch) -- the sky last; the first round renders the first places of the previous order "
+              "(RM_PATCH_ORDER=0 switches it off); sky tail: the places of the order nothing can be hit in get one wave instead of sixteen, "
+              "their number taken from a hint the earlier launches left in page-locked memory -- exact for a standing view, a guess for a "
+              "moved one, whose wrong places are rendered by sixteen waves each at the grid's end (RM_SKY_TAIL=0 switches it off); only the "
+              "order and the geometry of a launch depend on any of it: every frame classifies every patch and every pixel with something "
+              "to hit is traced in full, exactly once")
 MOTION_NOTE = ("the reference renders only after a camera move or a scene change (main.rs:74-78, :119-170): rm_camera_update before "
                "EVERY launch, the camera one button press (+-5 on one axis) from where it was (workloads.camera_walk), the scene "
                "resident; same stream, same outputs, same HIP-event bracket around the K steps as the metric")
@@ -797,8 +801,8 @@ def rank_main(args):
             n_slots = 4
             pf = [torch.zeros((h, w, 3), dtype=torch.float64, device=dev) for _ in range(n_slots)]
             pg = [torch.zeros((n_rows * 32, w, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)]
-            n_frames = max(steps, 30)
-            n_warm = n_slots * 10                        # (each slot's stream needs a few frames of its own: patch order, sky tail)
+            n_frames = max(10 * steps, 400)              # (30 frames were 2 ms of wall time: r3's 72.6 us against 62.7 over 600 frames, profiles/slots_cost.py)
+            n_warm = n_slots * 20                        # (each slot's stream needs a few frames of its own: order, first round, sky tail)
             for k in range(n_warm + n_frames):
                 if k == n_warm:
                     for b in range(n_slots):

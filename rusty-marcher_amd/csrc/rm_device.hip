@@ -235,6 +235,7 @@ struct rm_ctx {
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    bool mask_reuse = true;              // RM_MASK_REUSE=0: a launch waits for its own classification even where its predecessor's is as good (A/B knob)
     bool order_late_places = true;       // RM_ORDER_LATE_PLACES=0: the classifying workgroups always write the order's places themselves (A/B knob)
     bool order_reuse = true;             // RM_ORDER_REUSE=0: every launch dispatches by its own order, standing view or not (A/B knob)
     bool first_round_from_order = true;  // RM_FIRST_ROUND_FROM_ORDER=0: the first round is the bottom rows by place (A/B knob)
@@ -399,6 +400,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FIRST_ROUND_FROM_ORDER")) ctx->first_round_from_order = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
+    if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = std::atoi(env);
     if (const char *env = std::getenv("RM_TILE_ORDER"))
@@ -1114,6 +1116,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         grid.x = a.n_tiles + fb->cap;                         // ids [0, cap): the list; the rest: the tiles in order
     }
     if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging
+    uint32_t mask_tag_before_ = 0u;      // the tag the previous launch on this stream gave its tiles' words (0: none that this launch could take)
     // Tile classification in front of the render launch (rm_classify.hip): tiles whose primary rays can hit
     // nothing are filled there and never get a wave; the others are listed, with the primitives their primary
     // rays can reach.  Worth a launch of its own from a few thousand tiles on, in scenes whose primitives a
@@ -1121,6 +1124,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     {
         const uint32_t n_planar = ctx->H.n_polygons + ctx->H.n_triangles;
         const uint32_t cost = (22u * n_prims_all + 110u * n_planar) / 16u;   // a lane's share of the patch step
+        uint32_t &mask_tag_before = mask_tag_before_;
         const bool classify = ctx->classify_mode != 0 && !ctx->debug_empty && per_wg == 1u && n_prims_all > 0u &&
                               cost <= RM_CLASSIFY_MAX_COST && (ctx->classify_mode == 1 || a.n_tiles >= RM_CLASSIFY_MIN_TILES);
         ctx->last_launch_tiles = a.n_tiles;
@@ -1144,6 +1148,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                     tl->tagged = true; tl->tagged_tiles = a.n_tiles; tl->tagged_scene = ctx->scene_epoch;
                 }
                 a.mask_tag = ++tl->tag;
+                mask_tag_before = a.mask_tag > 1u ? a.mask_tag - 1u : 0u;     // (the previous launch's words are still there, under this tag)
                 a.cls_blocks = (a.n_tiles / 16u + 3u) / 4u;
                 a.cls_prims = n_prims_all;
                 grid.x += a.cls_blocks;
@@ -1237,6 +1242,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             a.ord_read_tag = reuse ? tl->last_tag : a.ord_tag;
             tl->last_tag = a.ord_tag;
             a.ord_rec = reuse && ctx->order_late_places ? tl->rec() : nullptr;
+            // (same view as the launch before: its classification is this launch's)
+            a.mask_tag_prev = reuse && ctx->mask_reuse ? mask_tag_before_ : 0u;
             a.patch_cost = timed ? tl->cost(f % 3u) : nullptr;
             a.cost_prev = timed ? tl->cost((f + 2u) % 3u) : nullptr;
             a.cost_zero = timed ? tl->cost((f + 1u) % 3u) : nullptr;

@@ -102,6 +102,9 @@ struct KernelArgs {
     // (mask_tag << 56) | mask; a render wave takes its tile's word once it carries this launch's tag.
     // mask_tag == 0: the masks come from a launch of their own, ahead of this one.
     uint32_t mask_tag;
+    // While the view stands still the previous launch's words are as good (same view, same classification): mask_tag_prev != 0
+    // says so, and every wave -- the first round's too -- takes its tile's word as it finds it.
+    uint32_t mask_tag_prev;
     uint32_t cls_blocks;
     uint32_t cls_prims;
     // Dispatch order from THIS launch's classification (rm_classify.inc `order_patches`, rm_render_kernel.inc `order_entry`).
