@@ -13,12 +13,12 @@ ctx.upload(pkg.Scene.create_default().flatten())
 w, h, depth = 1920, 1080, 5
 p = pkg.backend.make_params(1.5, float(h), float(w), depth)
 f64 = [torch.zeros((h, w, 3), dtype=torch.float64, device="cuda") for _ in range(4)]
-for world in (1, 2, 4, 8):
+for world in [int(x) for x in os.environ.get('WORLDS', '1,2,4,8').split(',')]:
     rows, chunk = ctx.exchange_layout(p, world)
     g8 = [torch.zeros((world * chunk,), dtype=torch.uint8, device="cuda") for _ in range(4)]
     ctx.comm_init(world - 1, world)           # the last rank: owns the bottom (expensive) rows' residue class
     line = []
-    for slots in (1, 2, 3, 4):
+    for slots in [int(x) for x in os.environ.get('SLOTS', '1,2,3,4').split(',')]:
         n = 600
         for k in range(n + 40):
             if k == 40:

@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void rm_scale_quantize_kernel(double *__restri
 // dropped: one atomic word serves ~70 claims/us, a 1080p frame needs >300 tiles/us.
 // This build instantiates one tile per wave, one wave per workgroup only; the other geometries
 // were measured with earlier builds.
+// (3,584: both share sizes of a 1080p frame at N = 8 -- 3,840 and 4,800 tiles -- take the same path; measured no difference in time)
+static constexpr uint32_t RM_CLASSIFY_MIN_TILES_DEFAULT = 3584;
 static constexpr uint32_t RM_CULL_MIN_PRIMS = 12, RM_CULL_EDGES_MIN_PLANAR = 4, RM_CULL_MAX_COST = 250;
 static inline uint32_t k_planar_from(const rm_dev_header &H) { return H.n_spheres; }   // pid of the first planar primitive
 
@@ -235,6 +237,7 @@ struct rm_ctx {
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    uint32_t classify_min_tiles = 0;     // RM_CLASSIFY_MIN_TILES: launches of this many tiles and more are classified (and ordered); 0: RM_CLASSIFY_MIN_TILES, the built-in
     bool mask_reuse = true;              // RM_MASK_REUSE=0: a launch waits for its own classification even where its predecessor's is as good (A/B knob)
     bool order_late_places = true;       // RM_ORDER_LATE_PLACES=0: the classifying workgroups always write the order's places themselves (A/B knob)
     bool order_reuse = true;             // RM_ORDER_REUSE=0: every launch dispatches by its own order, standing view or not (A/B knob)
@@ -401,6 +404,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_CLASSIFY_MIN_TILES")) ctx->classify_min_tiles = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = std::atoi(env);
     if (const char *env = std::getenv("RM_TILE_ORDER"))
@@ -411,6 +415,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
         ctx->cull_cos = std::max(0.05, std::atof(env));
     if (const char *env = std::getenv("RM_CULL_MIN")) ctx->cull_min_prims = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char *env = std::getenv("RM_CULL_EDGES")) ctx->cull_edges = env[0] != '0';
+    if (ctx->classify_min_tiles == 0u) ctx->classify_min_tiles = RM_CLASSIFY_MIN_TILES_DEFAULT;
     *out = ctx;
     return RM_OK;
 }
@@ -913,7 +918,7 @@ static rm_status feedback_for(rm_ctx *ctx, hipStream_t stream, const uint64_t ke
 // (launches of more than one round of wave slots -- 4,096 -- and a little: with the patches sorted by their longest tile the order
 // pays from there on: 640x480, 4,800 tiles, 35.9 -> 31.9 us, 800x600 34.1 -> 31.0, a quarter of a 1080p frame 44.4 -> 34.8;
 // 320x240, 1,120 tiles, which all start at once: 18.0 -> 19.3, left alone)
-static constexpr uint32_t RM_CLASSIFY_MIN_TILES = 4608, RM_CLASSIFY_STREAMS = 8;
+static constexpr uint32_t RM_CLASSIFY_STREAMS = 8;
 // Launches of this many patches and more take the kernels with the patch order for the sky tail alone (order_by_place):
 // measured 8K 987 -> 960 us; at 4K (8,100 patches) the sorting workgroup and the order's indirection cost what the tail saves
 // (245.3 against 243.8 us).
@@ -1016,7 +1021,7 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     // (launches of more patches than that take the same kernels for the sky tail alone: by_place, below)
     k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE &&
                (tiles / 16u <= ctx->patch_order_max || (ctx->sky_tail && ctx->sky_tail_big && n_prims <= 56u && tiles / 16u >= ctx->sky_tail_big_min)) &&
-               (ctx->patch_order_mode == 1 || tiles >= RM_CLASSIFY_MIN_TILES);
+               (ctx->patch_order_mode == 1 || tiles >= ctx->classify_min_tiles);
     k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order ? 1 : 0, k->feedback, st, pw);
     if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
     return RM_OK;
@@ -1126,7 +1131,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         const uint32_t cost = (22u * n_prims_all + 110u * n_planar) / 16u;   // a lane's share of the patch step
         uint32_t &mask_tag_before = mask_tag_before_;
         const bool classify = ctx->classify_mode != 0 && !ctx->debug_empty && per_wg == 1u && n_prims_all > 0u &&
-                              cost <= RM_CLASSIFY_MAX_COST && (ctx->classify_mode == 1 || a.n_tiles >= RM_CLASSIFY_MIN_TILES);
+                              cost <= RM_CLASSIFY_MAX_COST && (ctx->classify_mode == 1 || a.n_tiles >= ctx->classify_min_tiles);
         ctx->last_launch_tiles = a.n_tiles;
         ctx->last_launch_classified = classify;
         ctx->last_launch_stream = stream;
@@ -1232,9 +1237,12 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // While the view stands still a launch dispatches by the order its predecessor laid out -- same view, same
             // classification, the same first round: nothing to wait for -- and lays out the next launch's, from tile times a
             // frame fresher.  A view that has moved dispatches by its own order (the waves behind the first round wait for it).
-            // (from the view's THIRD launch on: its second still dispatches by its own order, with a first round taken from the
-            // first's -- this view's dearest patches, which the launches after it keep)
-            const bool reuse = ctx->order_reuse && f >= 2u && seq >= tl->view_seq0 + 2u && tl->last_tag != 0u;
+            // (from the view's FOURTH launch on.  A launch that dispatches by its predecessor's order keeps its predecessor's first
+            // round, and so do all after it: that first round had better be the view's dearest patches -- the first places of an
+            // order sorted by this view's own tile times, which the view's second launch is the first to lay out and its third
+            // the first to take its first round from.  Measured with the first round frozen a launch earlier, by place: a
+            // quarter of the 1080p frame 45 us a frame against 34.5.)
+            const bool reuse = ctx->order_reuse && f >= 3u && seq >= tl->view_seq0 + 3u && tl->last_tag != 0u;
             a.ord_flat = tl->flat(f & 1u);
             a.ord_cap = tl->order_cap;
             a.ord_tag = ++tl->ord_tag;
@@ -1253,7 +1261,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // The first round: the first places of the order the previous launch laid out (its classifying workgroups wrote them
             // down) -- unless this launch dispatches by that very order: then it keeps its predecessor's first round, which that
             // order leaves out.  Every launch writes the first places of the order it lays out for whoever comes next.
-            if (ctx->first_round_from_order && a.n_static / 16u <= n_dyn) {
+            if (ctx->first_round_from_order) {
                 const int read = reuse ? tl->static_read : tl->static_written;
                 const uint32_t write = read == 0 ? 1u : 0u;
                 a.static_list = read >= 0 ? tl->first((uint32_t)read) : nullptr;
@@ -1328,15 +1336,17 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     ctx->last_launch_grid = grid.x;
     ctx->last_launch_tail = a.tail_patches;
     if (a.ord_cnt && std::getenv("RM_DEBUG_TAIL")) {                    // (diagnostic: waits for the launch)
-        uint32_t c[RM_ORD_BUCKETS] = {}, raw[RM_ORD_ARRIVE] = {};
+        uint32_t c[RM_ORD_BUCKETS] = {}, c1[RM_ORD_BUCKETS] = {}, raw[RM_ORD_ARRIVE] = {};
         RM_HIP(ctx, hipStreamSynchronize(stream));
         RM_HIP(ctx, hipMemcpy(raw, a.ord_cnt, sizeof raw, hipMemcpyDeviceToHost));
-        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) c[b] = raw[b * RM_ORD_LINE];
+        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) { c[b] = raw[b * RM_ORD_LINE]; c1[b] = raw[RM_ORD_FIRST + b * RM_ORD_LINE]; }
         uint32_t lit = 0;
         for (uint32_t b = 0; b < RM_ORD_SKY; b++) lit += c[b];
         std::fprintf(stderr, "[rm_order] launch %u keys %u: %u classifying workgroups x %u, first round %u waves, %u + %u sky places; tail %u, room to hand on %u, handed on %u; buckets", a.launch_seq, a.key_mode,
                      a.cls_blocks, a.cls_iters, a.n_static, lit, c[RM_ORD_SKY], a.tail_patches, a.ov_cap, a.tail_patches > c[RM_ORD_SKY] ? std::min(a.ov_cap, a.tail_patches - c[RM_ORD_SKY]) : 0u);
         for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) std::fprintf(stderr, " %u", c[b]);
+        std::fprintf(stderr, " | first round's");
+        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) std::fprintf(stderr, " %u", c1[b]);
         // (the order this launch laid out: every place taken, by a patch of its own)
         const uint32_t n_pat = a.n_tiles / 16u, n_dyn_ = n_pat - a.n_static / 16u;
         std::vector<uint32_t> fl(n_dyn_);

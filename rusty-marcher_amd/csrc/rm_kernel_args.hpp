@@ -14,9 +14,11 @@
 #define RM_ORD_SKY 15u
 #define RM_ORD_MAX_CLS 1024u            /* classifying workgroups of a launch with an order: all resident, whatever the kernel's occupancy */
 /* the launch's counters, each in a 128-byte line of its own (waves that add to or ask for one word must not queue behind those of
-   another): [b] patches in bucket b | [16 + g] classifying workgroups of the g-th 32 that have arrived | [48] groups complete | [49] go */
+   another): [b] ordered patches in bucket b | [16 + b] first-round patches in bucket b | [32 + g] classifying workgroups of the g-th 32 that
+   have arrived | groups complete | go */
 #define RM_ORD_LINE 32u
-#define RM_ORD_ARRIVE (RM_ORD_BUCKETS * RM_ORD_LINE)
+#define RM_ORD_FIRST (RM_ORD_BUCKETS * RM_ORD_LINE)          /* [16 + b] patches of the FIRST ROUND in bucket b (for the next launch's first round) */
+#define RM_ORD_ARRIVE (2u * RM_ORD_BUCKETS * RM_ORD_LINE)
 #define RM_ORD_GROUPS (RM_ORD_ARRIVE + (RM_ORD_MAX_CLS / 32u) * RM_ORD_LINE)
 #define RM_ORD_GO (RM_ORD_GROUPS + RM_ORD_LINE)
 #define RM_ORD_CNT_WORDS (RM_ORD_GO + RM_ORD_LINE)
