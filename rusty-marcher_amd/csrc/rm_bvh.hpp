@@ -20,7 +20,18 @@
 #include <limits>
 #include <vector>
 
+#ifndef RM_BVH4
+#define RM_BVH4 0
+#endif
+#if RM_BVH4
+// Four-wide nodes (32 words, one 256-byte fetch): the binary tree with every other level folded away.
+//   [6 c .. 6 c + 5]  child c's box, min xyz | max xyz      (c = 0..3: left-left, left-right, right-left, right-right)
+//   [24 .. 27]        child c's ref as two u32: index (inner: node, leaf: first primitive), count (0: inner; ~0: no such child)
+//   [28]              u32: split axes -- bits 0-1 the node's own, 2-3 its left half's, 4-5 its right half's (front-to-back order)
+#define RM_BVH_NODE_WORDS 32u
+#else
 #define RM_BVH_NODE_WORDS 16u
+#endif
 
 struct rm_aabb {
     double lo[3], hi[3];
@@ -61,6 +72,7 @@ struct Builder {
     const std::vector<rm_aabb> &boxes;
     uint32_t leaf_size;
     rm_bvh &out;
+    std::vector<int> axis_of;         // per binary inner node: the axis its halves were sorted along
 
     // Builds the subtree over order[first, first+count) whose root sits `depth` levels below
     // the hierarchy's root; returns its ref and box.
@@ -92,18 +104,19 @@ struct Builder {
                 if (balanced && cost < best_cost) { best_cost = cost; half = k; axis = a; best_order = tmp; }
             }
         }
-        (void)axis;
         if (depth >= RM_BVH_SAH_DEPTH && best_order.empty()) half = count / 2;   // (costs were not finite)
         out.depth = std::max(out.depth, depth + 1u);
         if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), out.order.begin() + first);
-        const uint32_t me = (uint32_t)(out.nodes.size() / RM_BVH_NODE_WORDS);
-        out.nodes.resize(out.nodes.size() + RM_BVH_NODE_WORDS, 0.);
+        const uint32_t me = (uint32_t)(out.nodes.size() / 16u);
+        out.nodes.resize(out.nodes.size() + 16u, 0.);
+        axis_of.resize(me + 1u, 0);
+        axis_of[me] = axis;
         rm_aabb lb, rb;
         const uint64_t lref = build(first, half, lb, depth + 1u);
         const uint64_t rref = build(first + half, count - half, rb, depth + 1u);
         inflate(lb);
         inflate(rb);
-        double *n = &out.nodes[(size_t)me * RM_BVH_NODE_WORDS];
+        double *n = &out.nodes[(size_t)me * 16u];
         for (int a = 0; a < 3; a++) { n[a] = lb.lo[a]; n[3 + a] = lb.hi[a]; n[6 + a] = rb.lo[a]; n[9 + a] = rb.hi[a]; }
         std::memcpy(&n[12], &lref, 8);
         std::memcpy(&n[13], &rref, 8);
@@ -119,9 +132,58 @@ inline rm_bvh rm_build_bvh(const std::vector<rm_aabb> &boxes, uint32_t leaf_size
     rm_bvh out;
     out.order.resize(boxes.size());
     for (uint32_t i = 0; i < boxes.size(); i++) out.order[i] = i;
-    rm_bvh_detail::Builder b{boxes, leaf_size, out};
+    rm_bvh_detail::Builder b{boxes, leaf_size, out, {}};
     rm_aabb root;
     b.build(0, (uint32_t)boxes.size(), root, 0);
+#if RM_BVH4
+    // fold every other level away: a node's children are its halves' halves (a half that is a leaf stays one child)
+    const std::vector<double> bin = out.nodes;
+    std::vector<double> wide;
+    uint32_t depth4 = 0;
+    struct Fold {
+        const std::vector<double> &bin; const std::vector<int> &axis_of; std::vector<double> &wide; uint32_t &depth4;
+        uint32_t fold(uint32_t node, uint32_t depth) {
+            depth4 = std::max(depth4, depth + 1u);
+            const uint32_t me = (uint32_t)(wide.size() / RM_BVH_NODE_WORDS);
+            wide.resize(wide.size() + RM_BVH_NODE_WORDS, 0.);
+            const double *n = &bin[(size_t)node * 16u];
+            uint64_t ref[2];
+            std::memcpy(&ref[0], &n[12], 8); std::memcpy(&ref[1], &n[13], 8);
+            double box[4][6];
+            uint32_t idx[4], cnt[4];
+            uint32_t axes = (uint32_t)axis_of[node] & 3u;
+            for (int h = 0; h < 2; h++) {
+                const uint32_t hi = (uint32_t)(ref[h] >> 32), lo = (uint32_t)ref[h];
+                for (int c = 0; c < 2; c++) { idx[2 * h + c] = 0u; cnt[2 * h + c] = ~0u; for (int k = 0; k < 6; k++) box[2 * h + c][k] = 0.; }
+                if (hi != 0u) {                                   // a leaf: one child
+                    for (int k = 0; k < 6; k++) box[2 * h][k] = n[6 * h + k];
+                    idx[2 * h] = lo; cnt[2 * h] = hi;
+                } else {                                          // an inner node: its two halves
+                    const double *m = &bin[(size_t)lo * 16u];
+                    uint64_t r2[2];
+                    std::memcpy(&r2[0], &m[12], 8); std::memcpy(&r2[1], &m[13], 8);
+                    axes |= ((uint32_t)axis_of[lo] & 3u) << (2 + 2 * h);
+                    for (int c = 0; c < 2; c++) {
+                        for (int k = 0; k < 6; k++) box[2 * h + c][k] = m[6 * c + k];
+                        const uint32_t hi2 = (uint32_t)(r2[c] >> 32), lo2 = (uint32_t)r2[c];
+                        if (hi2 != 0u) { idx[2 * h + c] = lo2; cnt[2 * h + c] = hi2; }
+                        else { idx[2 * h + c] = fold(lo2, depth + 1u); cnt[2 * h + c] = 0u; }
+                    }
+                }
+            }
+            double *w = &wide[(size_t)me * RM_BVH_NODE_WORDS];   // (after the recursion: `wide` may have moved)
+            for (int c = 0; c < 4; c++) for (int k = 0; k < 6; k++) w[6 * c + k] = box[c][k];
+            uint32_t refs[8];
+            for (int c = 0; c < 4; c++) { refs[2 * c] = idx[c]; refs[2 * c + 1] = cnt[c]; }
+            std::memcpy(&w[24], refs, sizeof refs);
+            std::memcpy(&w[28], &axes, 4);
+            return me;
+        }
+    } f{bin, b.axis_of, wide, depth4};
+    f.fold(0u, 0u);
+    out.nodes.swap(wide);
+    out.depth = 3u * depth4;          // entries the walk can park: three per level
+#endif
     return out;
 }
 

@@ -232,11 +232,13 @@ struct rm_ctx {
     bool classify_in_launch = true;      // RM_CLASSIFY_IN_LAUNCH=0: always a launch of its own in front (A/B knob)
     bool sky_tail = true;                // RM_SKY_TAIL=0: every patch gets its sixteen waves
     uint32_t patch_order_max = 4096;     // RM_PATCH_ORDER_MAX: launches of up to this many patches take the kernels with the patch order
+    uint32_t patch_order_max_deep = 65536;   // RM_PATCH_ORDER_MAX_DEEP: ... in scenes with a hierarchy (tile times with a long tail)
     uint32_t sky_tail_big_min = 16384;   // RM_SKY_TAIL_BIG_MIN (patches; see RM_SKY_TAIL_BIG_MIN_PATCHES)
-    bool sky_tail_big = true;            // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
+    bool sky_tail_big = false;            // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    uint32_t classify_in_launch_prims = 56;   // RM_CLASSIFY_IN_LAUNCH_PRIMS: scenes of up to this many primitives are classified at the head of the render launch
     uint32_t classify_min_tiles = 0;     // RM_CLASSIFY_MIN_TILES: launches of this many tiles and more are classified (and ordered); 0: RM_CLASSIFY_MIN_TILES, the built-in
     bool mask_reuse = true;              // RM_MASK_REUSE=0: a launch waits for its own classification even where its predecessor's is as good (A/B knob)
     bool order_late_places = true;       // RM_ORDER_LATE_PLACES=0: the classifying workgroups always write the order's places themselves (A/B knob)
@@ -394,6 +396,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_SKY_TAIL_FORCE")) ctx->sky_tail_force = std::atoi(env);
     if (const char *env = std::getenv("RM_PATCH_ORDER_MAX")) ctx->patch_order_max = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG")) ctx->sky_tail_big = env[0] != '0';
+    if (const char *env = std::getenv("RM_PATCH_ORDER_MAX_DEEP")) ctx->patch_order_max_deep = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG_MIN")) ctx->sky_tail_big_min = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_PLACE")) ctx->sky_tail_place = env[0] == 'e' && env[1] == 'v' ? 1 : env[0] == 'e' ? 2 : 0;
     if (const char *env = std::getenv("RM_SKY_TAIL_MOTION")) ctx->sky_tail_motion = env[0] != '0';
@@ -404,6 +407,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_CLASSIFY_IN_LAUNCH_PRIMS")) ctx->classify_in_launch_prims = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_CLASSIFY_MIN_TILES")) ctx->classify_min_tiles = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_TEST_STALL_ORDER")) ctx->test_stall_order = std::atoi(env);
@@ -927,6 +931,8 @@ static constexpr uint32_t RM_SKY_TAIL_BIG_MIN_PATCHES = 16384;   // (rm_ctx::sky
 // per bounding sphere, ~110 more for the edge and plane tests of a planar primitive.  Beyond this the launch
 // is not worth its time.
 static constexpr uint32_t RM_CLASSIFY_MAX_COST = 4000;
+// ... and at the head of the render launch itself, where every wave behind the first round may wait for it: a quarter of that
+static constexpr uint32_t RM_CLASSIFY_IN_LAUNCH_MAX_COST = 1000;
 
 static rm_status tile_lists_for(rm_ctx *ctx, hipStream_t stream, uint32_t n_tiles, rm_tile_lists **out) {
     rm_tile_lists *t = nullptr;
@@ -980,6 +986,7 @@ struct rm_kernel_choice {
     size_t lds_bytes = 0;
     int stack = 0, pow_mode = 0;
     bool fast = false, staged = false, bvh = false, cull = false, edges = false, order = false, feedback = false;
+    bool order_in_big_scene = false;  // a scene with a hierarchy whose launches are classified at their own head and dispatched by that
 };
 
 static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, rm_kernel_choice *k) {
@@ -1015,13 +1022,22 @@ static rm_status choose_kernel(rm_ctx *ctx, const rm_params *p, uint32_t tiles, 
     // ground: dispatched first) and the bookkeeping only costs -- measured with it forced on: demo
     // scene 1080p 85.0 -> 87.7 us, 4K 306 -> 328, 8K depth 8 1,205 -> 1,375, Cornell box 72 -> 77.
     // RM_FEEDBACK=1 forces it for every launch of a kernel with the hierarchy walk, =0 switches it off.
-    k->feedback = k->bvh && ctx->feedback_mode != 0 && !ctx->debug_empty &&
+    // r4: scenes with a hierarchy take the dispatch order from the launch's own classification instead where that can run
+    // at the launch's head (patches timed by their longest tile, the sky tail on top): 256 spheres 4096x4096 1,174-1,185 ->
+    // 1,160 us.  The tile-level feedback stays for what is left (RM_FEEDBACK=1 forces it).
+    const uint32_t n_planar = ctx->H.n_polygons + ctx->H.n_triangles;
+    k->order_in_big_scene = k->bvh && ctx->patch_order_mode != 0 && ctx->feedback_mode != 1 && !ctx->debug_empty && ctx->classify_mode != 0 &&
+                            ctx->classify_in_launch && ctx->tile_order == TILE_ORDER_REVERSE && (22u * n_prims + 110u * n_planar) / 16u <= RM_CLASSIFY_IN_LAUNCH_MAX_COST &&
+                            tiles / 16u <= ctx->patch_order_max_deep && (ctx->patch_order_mode == 1 || tiles >= ctx->classify_min_tiles);
+    k->feedback = k->bvh && !k->order_in_big_scene && ctx->feedback_mode != 0 && !ctx->debug_empty &&
                   (ctx->feedback_mode == 1 || (p->max_depth >= 6u && tiles >= RM_FEEDBACK_MIN_TILES));
-    // the patch-order feedback: launches of up to 4,096 patches that do not carry the tile-level feedback
-    // (launches of more patches than that take the same kernels for the sky tail alone: by_place, below)
-    k->order = ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE &&
-               (tiles / 16u <= ctx->patch_order_max || (ctx->sky_tail && ctx->sky_tail_big && n_prims <= 56u && tiles / 16u >= ctx->sky_tail_big_min)) &&
-               (ctx->patch_order_mode == 1 || tiles >= ctx->classify_min_tiles);
+    // the dispatch order: launches of up to 4,096 patches that do not carry the tile-level feedback (launches of more patches
+    // than that may take the same kernels for the sky tail alone -- RM_SKY_TAIL_BIG=1: by place, below; r4: measured to buy
+    // nothing any more, 8K 988.9 against 985.6 us for the kernels without)
+    k->order = k->order_in_big_scene ||
+               (ctx->patch_order_mode != 0 && !k->feedback && !ctx->debug_empty && ctx->tile_order == TILE_ORDER_REVERSE &&
+                (tiles / 16u <= ctx->patch_order_max || (ctx->sky_tail && ctx->sky_tail_big && n_prims <= 56u && tiles / 16u >= ctx->sky_tail_big_min)) &&
+                (ctx->patch_order_mode == 1 || tiles >= ctx->classify_min_tiles));
     k->fn = rm_pick_kernel(f, k->staged, k->bvh, k->cull, k->edges, k->order ? 1 : 0, k->feedback, st, pw);
     if (!k->fn) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "render: no kernel for this scene / depth combination");
     return RM_OK;
@@ -1144,7 +1160,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // runs while the first round of tiles renders.  Measured at 1080p, demo scene: 82.6 us with the launch
             // in front, against 82.1 without any classification.  Larger scenes, and launches that carry the
             // frame-to-frame feedback, get the launch in front.
-            const bool in_launch = ctx->classify_in_launch && n_prims_all <= 56u && !want_feedback;
+            // (RM_CLASSIFY_IN_LAUNCH_PRIMS: larger scenes too -- their words then only say whether there is anything to hit)
+            const bool in_launch = ctx->classify_in_launch && (n_prims_all <= ctx->classify_in_launch_prims || k.order_in_big_scene) && !want_feedback;
             if (in_launch) {
                 if (!tl->tagged || tl->tagged_tiles != a.n_tiles || tl->tagged_scene != ctx->scene_epoch || tl->tag >= 255u) {
                     // (a word is taken by its tag: after anything that could leave an old word with a tag in use, start afresh)
@@ -1225,7 +1242,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 std::memcpy(tl->view, view, sizeof view);
                 tl->view_seq0 = seq;
             }
-            const bool timed = n_patches <= ctx->patch_order_max;             // (larger launches are many rounds deep: by place, for the sky tail alone)
+            const bool timed = n_patches <= (k.order_in_big_scene ? ctx->patch_order_max_deep : ctx->patch_order_max);             // (larger launches are many rounds deep: by place, for the sky tail alone)
             // the classifying workgroups wait for each other: they must all be resident, whatever the kernel's occupancy --
             // at most 1,024 of them, each taking as many groups of four patches, one after the other, as that needs
             grid.x -= a.cls_blocks;

@@ -8,7 +8,14 @@
 
 #include "rm_internal.h"
 
+#ifndef RM_BVH4
+#define RM_BVH4 0
+#endif
+#if RM_BVH4
+#define RM_BVH_NODE_WORDS 32u
+#else
 #define RM_BVH_NODE_WORDS 16u
+#endif
 // dispatch order built at the launch's head (KernelArgs::ord_*): sixteen buckets, the last one the sky
 #define RM_ORD_BUCKETS 16u
 #define RM_ORD_SKY 15u

@@ -132,13 +132,14 @@ def test_config_c5_synthetic_bands(pkg, O, ctx):
     """4096x4096, 256 spheres, depth 10: the oracle needs minutes for the full frame,
     so eight patch rows spread over the image are checked pixel for pixel; the rest is
     covered by the property tests below.
-    THREE frames on the context's stream, like the frames bench.py times: this launch geometry
-    (262,144 tiles, depth cap 10, hierarchy kernel) carries the frame-to-frame feedback, whose
-    list of long tiles is empty for the first frame and drives the dispatch of the second and
-    third (list first: capacity 32,768, target 16,384; then the tiles in order less the flagged
-    ones).  Each frame goes into a caller-owned device buffer pre-filled with a sentinel, so a
-    tile that was left out -- or rendered into the wrong place -- cannot hide behind the previous
-    frame's pixels; all three must hold the oracle's rows and equal each other bit for bit."""
+    FIVE frames on the context's stream, like the frames bench.py times: this launch geometry (262,144 tiles = 16,384 patches,
+    depth cap 10, hierarchy kernel) is classified at its own head -- 257 primitives: a word only says whether there is anything
+    to hit -- and dispatched by the order that gives (r4; the tile-level feedback it carried until r3 is what
+    test_feedback_order_renders_every_tile_once forces on): by place in the first frame, by the patches' longest tiles in the
+    second and third (which dispatch by their own order), by their predecessor's order from the fourth on, the sky in the tail.
+    Each frame goes into a caller-owned device buffer pre-filled with a sentinel, so a tile that was left out -- or rendered into
+    the wrong place -- cannot hide behind the previous frame's pixels; all five must hold the oracle's rows and equal each
+    other bit for bit."""
     import torch
     c = workloads.CONFIGS["C5"]
     w, h, depth = c["width"], c["height"], c["max_depth"]
@@ -146,7 +147,7 @@ def test_config_c5_synthetic_bands(pkg, O, ctx):
     p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
     p.flags = _FLAGS["value"]
     targs = [x.strip() for x in ctx.kernel_name(p).split("<", 1)[1].rstrip(">").split(",")]   # ..., ORDER, FEEDBACK, HANDON
-    assert targs[9] == "true", "C5 is expected to run the kernel with the feedback"
+    assert targs[8] == "true" and targs[9] == "false", "C5 is expected to run the kernel with the dispatch order"
     so = workloads.oracle_scene(O, "synthetic256")
     ref = np.zeros((h, w, 3), dtype=np.float64)
     rows = [0, 23, 47, 64, 77, 96, 111, 127]
@@ -154,7 +155,7 @@ def test_config_c5_synthetic_bands(pkg, O, ctx):
         O.render(so, w, h, max_depth=depth, frame=ref, band=(r, r + 1))
     dev = torch.empty((h, w, 3), dtype=torch.float64, device="cuda:0")
     first = None
-    for frame_no in range(3):
+    for frame_no in range(5):
         dev.fill_(-1.)
         torch.cuda.synchronize()
         ctx.render_device(p, dev.data_ptr())            # (HIP's default stream: the same one every time)
@@ -831,9 +832,11 @@ def test_sky_tail_renders_every_patch_once(pkg, monkeypatch):
     monkeypatch.setenv("RM_FIRST_ROUND", "256")
     monkeypatch.setenv("RM_PATCH_ORDER_MAX", "100")                 # (larger launches: no tile is timed, the order is bottom-up less the sky)
     monkeypatch.setenv("RM_SKY_TAIL_BIG_MIN", "0")
+    monkeypatch.setenv("RM_SKY_TAIL_BIG", "1")
     by_place = pkg.backend.Context(0)
     monkeypatch.delenv("RM_PATCH_ORDER_MAX")
     monkeypatch.delenv("RM_SKY_TAIL_BIG_MIN")
+    monkeypatch.delenv("RM_SKY_TAIL_BIG")
     monkeypatch.setenv("RM_SKY_TAIL_FORCE", "37")
     wrong_some = pkg.backend.Context(0)
     monkeypatch.setenv("RM_SKY_TAIL_CAP", "5")
