@@ -264,8 +264,8 @@ rm_status rm_render_rows(rm_ctx *ctx, const rm_params *params, double *const *ro
  * only `fb.to_vec()` of the band -- the bytes update_raytrace_image hands to the pixbuf,
  * main.rs:337-346; (255 * clamp(f, 0, 1)) as u8, framebuffer.rs:40-55,80-82 -- comes back:
  * host_rgb8 is [frame_height][frame_width][3] bytes, only the band's rows are written.  3 B/pixel
- * instead of 24, and the frame is rendered as a few sub-bands (RM_DISPLAY_SUBBANDS, default 3),
- * the bytes of one crossing the link while the next renders.  Blocks until host_rgb8 is filled.
+ * instead of 24: one launch, then one copy-engine transfer (RM_DISPLAY_SUBBANDS=n renders n sub-bands, the bytes
+ * of one crossing the link while the next renders: measured and slower, default 1).  Blocks until host_rgb8 is filled.
  * host_rgb8 from rm_host_alloc is written by the copy engine directly; any other memory is
  * reached through the context's staging buffer.
  */

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -297,6 +298,21 @@ static rm_status ctx_fail(rm_ctx *ctx, rm_status st, const std::string &msg) {
     return st;
 }
 
+// Nothing unwinds across the C ABI: what an entry point's body may throw (std::vector / std::function growing: bad_alloc)
+// comes back as a status like every other failure.
+template <class F>
+static rm_status guarded(rm_ctx *ctx, const char *who, F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return ctx_fail(ctx, RM_ERR_INVALID_ARG, std::string(who) + ": out of host memory");
+    } catch (const std::exception &e) {
+        return ctx_fail(ctx, RM_ERR_INVALID_ARG, std::string(who) + ": " + e.what());
+    } catch (...) {
+        return ctx_fail(ctx, RM_ERR_INVALID_ARG, std::string(who) + ": unexpected exception");
+    }
+}
+
 #define RM_HIP(ctx, call)                                                                          \
     do {                                                                                           \
         hipError_t e__ = (call);                                                                   \
@@ -473,7 +489,7 @@ rm_status rm_device_info(rm_ctx *ctx, char *name_buf, size_t buflen, int *n_cus,
 
 static uint64_t pack_u32x2(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
-rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
+static rm_status rm_scene_upload_impl(rm_ctx *ctx, const rm_scene_desc *d) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_scene_upload: NULL ctx");
     if (!d) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_scene_upload: NULL desc");
     if ((d->n_shapes && !d->shapes) || (d->n_spheres && !d->spheres) || (d->n_polygons && !d->polygons) ||
@@ -816,6 +832,10 @@ rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
     ctx->host_blob.swap(blob);
     keep_description();
     return RM_OK;
+}
+
+rm_status rm_scene_upload(rm_ctx *ctx, const rm_scene_desc *d) {
+    return guarded(ctx, "rm_scene_upload", [&]() { return rm_scene_upload_impl(ctx, d); });
 }
 
 rm_status rm_scene_uploads(rm_ctx *ctx, uint64_t *calls, uint64_t *copies) {
@@ -1397,7 +1417,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     return RM_OK;
 }
 
-rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream) {
+static rm_status rm_render_device_impl(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render_device: NULL ctx");
     if (!device_rgb) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render_device: NULL device buffer");
     rm_band band;
@@ -1408,7 +1428,11 @@ rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rg
     return launch_render(ctx, params, band, (double *)device_rgb, nullptr, s);
 }
 
-rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
+rm_status rm_render_device(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *hip_stream) {
+    return guarded(ctx, "rm_render_device", [&]() { return rm_render_device_impl(ctx, params, device_rgb, hip_stream); });
+}
+
+static rm_status rm_render_device_u8_impl(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
                               void *hip_stream) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render_device_u8: NULL ctx");
     if (!device_rgb || !device_rgb8) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_render_device_u8: NULL device buffer");
@@ -1421,7 +1445,12 @@ rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device
     return launch_render(ctx, params, band, (double *)device_rgb, (uint8_t *)device_rgb8, (hipStream_t)hip_stream);
 }
 
-rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing) {
+rm_status rm_render_device_u8(rm_ctx *ctx, const rm_params *params, void *device_rgb, void *device_rgb8,
+                              void *hip_stream) {
+    return guarded(ctx, "rm_render_device_u8", [&]() { return rm_render_device_u8_impl(ctx, params, device_rgb, device_rgb8, hip_stream); });
+}
+
+static rm_status rm_render_impl(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_render: NULL ctx");
     const auto t_begin = std::chrono::steady_clock::now();
     rm_band band;
@@ -1490,6 +1519,10 @@ rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_t
     return RM_OK;
 }
 
+rm_status rm_render(rm_ctx *ctx, const rm_params *params, double *host_rgb, rm_timing *timing) {
+    return guarded(ctx, "rm_render", [&]() { return rm_render_impl(ctx, params, host_rgb, timing); });
+}
+
 rm_status rm_kernel_name(rm_ctx *ctx, const rm_params *params, char *buf, size_t buflen) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_kernel_name: NULL ctx");
     if (!buf || buflen == 0) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_kernel_name: NULL buffer");
@@ -1514,7 +1547,7 @@ rm_status rm_launch_stats(rm_ctx *ctx, uint32_t *workgroups, uint32_t *tail_patc
     return RM_OK;
 }
 
-rm_status rm_tile_stats(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t *tiles_listed) {
+static rm_status rm_tile_stats_impl(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t *tiles_listed) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_tile_stats: NULL ctx");
     RM_HIP(ctx, hipSetDevice(ctx->device));
     RM_HIP(ctx, hipDeviceSynchronize());
@@ -1546,6 +1579,10 @@ rm_status rm_tile_stats(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t
     return RM_OK;
 }
 
+rm_status rm_tile_stats(rm_ctx *ctx, void *hip_stream, uint32_t *tiles, uint32_t *tiles_listed) {
+    return guarded(ctx, "rm_tile_stats", [&]() { return rm_tile_stats_impl(ctx, hip_stream, tiles, tiles_listed); });
+}
+
 rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_device_framebuffer: NULL ctx");
     if (!ctx->d_frame) return ctx_fail(ctx, RM_ERR_INVALID_ARG, "rm_device_framebuffer: nothing rendered yet");
@@ -1554,7 +1591,7 @@ rm_status rm_device_framebuffer(rm_ctx *ctx, void **device_rgb, size_t *bytes) {
     return RM_OK;
 }
 
-rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, int normalize, uint8_t *host_rgb8,
+static rm_status rm_postprocess_impl(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, int normalize, uint8_t *host_rgb8,
                          double *max_out) {
     if (!ctx) return ctx_fail(nullptr, RM_ERR_INVALID_ARG, "rm_postprocess: NULL ctx");
     RM_HIP(ctx, hipSetDevice(ctx->device));
@@ -1598,6 +1635,11 @@ rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, 
         std::memcpy(max_out, &bits, sizeof bits);
     }
     return RM_OK;
+}
+
+rm_status rm_postprocess(rm_ctx *ctx, void *device_rgb, uint32_t w, uint32_t h, int normalize, uint8_t *host_rgb8,
+                         double *max_out) {
+    return guarded(ctx, "rm_postprocess", [&]() { return rm_postprocess_impl(ctx, device_rgb, w, h, normalize, host_rgb8, max_out); });
 }
 
 }  // extern "C"

@@ -76,6 +76,22 @@ int main(int argc, char **argv) {
         int threads = 0;
         check(rm_hostio_stats(ctx, &bytes, &patches, &sent, &threads), ctx);
 
+        // ---- ... the way the reference calls it: a button offsets the camera by 5 on one axis, then render() (main.rs:74-78,
+        // :119-170).  Twelve presses that lead back home, over and over: every call renders a view its predecessor did not.
+        std::vector<double> t_move, t_move_kernel;
+        {
+            const Vec3f press[12] = {{5, 0, 0}, {0, 5, 0}, {0, 0, 5}, {-5, 0, 0}, {0, 0, 5}, {5, 0, 0}, {0, -5, 0}, {0, 0, -5}, {-5, 0, 0}, {0, 5, 0}, {0, 0, -5}, {0, -5, 0}};
+            const unsigned n_move = ((frames + 11u) / 12u) * 12u;
+            for (unsigned f = 0; f < 12u + n_move; f++) {
+                sc.offset_camera(press[f % 12u]);
+                const auto t0 = clk::now();
+                r.render(fb, sc);
+                const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+                if (f >= 12u) { t_move.push_back(ms); t_move_kernel.push_back(r.last_timing.kernel_ms); }
+            }
+            r.render(fb, sc);                                           // (home again: the frame the comparisons below expect)
+        }
+
         // ---- flat pageable array through rm_render (same scene, same context)
         bool owned = false;
         rm_scene *flat_scene = sc.flatten(&owned);
@@ -185,7 +201,8 @@ int main(int argc, char **argv) {
                      "{\"scene\": \"%s\", \"width\": %zu, \"height\": %zu, \"depth\": %u, \"frames\": %u, \"host_threads\": %d, "
                      "\"rows_of_rows\": {\"ms_per_call\": %.4f, \"mpx_per_s\": %.1f, \"kernel_ms\": %.4f, \"bytes_over_the_link\": %llu, "
                      "\"patches\": %llu, \"patches_sent\": %llu, \"identical_to_flat\": %s, "
-                     "\"what\": \"Renderer::render into a FrameBuffer of per-row heap allocations (rm_render_rows), median\"}, "
+                     "\"what\": \"Renderer::render into a FrameBuffer of per-row heap allocations (rm_render_rows), median\", "
+                     "\"camera_on_the_move\": {\"ms_per_call\": %.4f, \"kernel_ms\": %.4f, \"what\": \"scene.offset_camera(one press: 5 on one axis) before every render(), median\"}}, "
                      "\"flat\": {\"ms_per_call\": %.4f, \"mpx_per_s\": %.1f, \"what\": \"rm_render into one flat pageable array, median\"}, "
                      "\"display_only\": {\"ms_per_call\": %.4f, \"frames_per_s\": %.1f, \"kernel_ms\": %.4f, \"identical_to_to_vec_of_rows\": %s, "
                      "\"into_page_locked\": {\"ms_per_call\": %.4f, \"frames_per_s\": %.1f, \"identical\": %s}, "
@@ -195,7 +212,7 @@ int main(int argc, char **argv) {
                      "\"fetch_rows\": {\"ms_per_call\": %.4f, \"identical\": %s}}\n",
                      scene_arg.c_str(), width, height, depth, frames, threads, m_rows, px / m_rows / 1e3, median(t_rows_kernel),
                      (unsigned long long)bytes, (unsigned long long)patches, (unsigned long long)sent, rows_equal_flat ? "true" : "false",
-                     m_flat, px / m_flat / 1e3, m_disp, 1e3 / m_disp, median(t_disp_kernel), display_equal ? "true" : "false", m_pin,
+                     median(t_move), median(t_move_kernel), m_flat, px / m_flat / 1e3, m_disp, 1e3 / m_disp, median(t_disp_kernel), display_equal ? "true" : "false", m_pin,
                      1e3 / m_pin, pinned_equal ? "true" : "false", pipelined_fps, (unsigned)RM_MAX_FRAME_SLOTS, pipelined_equal ? "true" : "false",
                      median(t_fetch), fetch_equal ? "true" : "false");
         std::fclose(json);

@@ -86,6 +86,10 @@ def test_repeated_render_calls_upload_the_scene_once(rm_demo, golden_ppm, tmp_pa
     assert "scene uploads: 6 calls, 1 copies to the device" in log
     call_ms = float([ln for ln in log.splitlines() if ln.startswith("kernel ")][-1].split("call ")[1].split(" ms")[0])
     print("rm_demo 1080p: render() call %.3f ms" % call_ms)
+    # (the call's host side shares the box with other tenants -- 0.62 to 1.15 ms were read minutes apart -- so the bound is a
+    # generous one; the device's part is held tighter)
+    kernel_ms = float([ln for ln in log.splitlines() if ln.startswith("kernel ")][-1].split("kernel ")[1].split(" ms")[0])
+    assert call_ms < 20.0 and kernel_ms < 0.5, (call_ms, kernel_ms)
     sent, total = [int(x) for x in [ln for ln in log.splitlines() if ln.startswith("last frame:")][-1].split("link, ")[1].split(" patches")[0].split(" of ")]
     assert total == 1980 and 0 < sent < total
 
