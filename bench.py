@@ -67,7 +67,7 @@ ORDER_NOTE = ("dispatch order from the launch's own classification: its classify
 MOTION_NOTE = ("the reference renders only after a camera move or a scene change (main.rs:74-78, :119-170): rm_camera_update before "
                "EVERY launch, the camera one button press (+-5 on one axis) from where it was (workloads.camera_walk), the scene "
                "resident; same stream, same outputs, same HIP-event bracket around the K steps as the metric")
-WARMUP_SECONDS = 0.3            # launches before the timed region, on top of --warmup (clocks settle)
+WARMUP_SECONDS = float(os.environ.get("RM_BENCH_WARMUP_S", "0.3"))   # launches before the timed region, on top of --warmup (clocks settle; the profiling passes shorten it)
 WARMUP_PROBE = 8                # launches timed to find out how many that is
 
 

@@ -12,7 +12,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in C2 C3 C5 C4; do
   steps=200; [ $c = C5 ] && steps=20; [ $c = C4 ] && steps=20
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$c -- python3 $R/bench.py --config $c --steps $steps --warmup 10 --no-cpu-baseline --no-sizes > $R/gpurun_out/${TAG}_trace_$c.json 2> $R/gpurun_out/${TAG}_trace_$c.err || echo "trace $c failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_$c -- python3 $R/bench.py --config $c --steps $steps --warmup 10 --no-cpu-baseline --no-sizes --no-motion > $R/gpurun_out/${TAG}_trace_$c.json 2> $R/gpurun_out/${TAG}_trace_$c.err || echo "trace $c failed"
+  find $R/gpurun_out/${TAG}_trace_$c -name "*kernel_trace.csv" -delete      # (one row per launch: megabytes; the stats file is what is kept)
   echo "trace $c done"
 done
 cd $R
@@ -25,5 +26,6 @@ echo "bench done"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2> gpurun_out/${TAG}_bench_driver_cmd.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace_default -- python3 $R/bench.py > $R/gpurun_out/${TAG}_trace_default.json 2> $R/gpurun_out/${TAG}_trace_default.err || echo "trace default failed"
+find $R/gpurun_out/${TAG}_trace_default -name "*kernel_trace.csv" -delete
 cd $R
 ls gpurun_out | grep ${TAG}_ | head -60

@@ -19,7 +19,8 @@ for grp in \
   "FETCH_SIZE" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $BENCH --steps 5 --warmup 2 --no-cpu-baseline --no-sizes "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
+  # (a short warm-up: every launch is a few hundred rows of counters, and what comes back from the box is bounded)
+  RM_BENCH_WARMUP_S=0.02 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $BENCH --steps 5 --warmup 2 --no-cpu-baseline --no-sizes --no-motion "$@" > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
@@ -39,3 +40,4 @@ with open(out + "/summary.csv", "w") as g:
         g.write("%s,%s,%.1f,%d\n" % (k[0], k[1], agg[k][0] / agg[k][1], agg[k][1]))
 print(open(out + "/summary.csv").read())
 PY
+rm -rf $OUT/g[0-9]     # (the raw per-launch rows stay on the box: the summary and the bench lines are what is kept)

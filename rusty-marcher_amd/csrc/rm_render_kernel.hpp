@@ -48,6 +48,14 @@ __device__ __forceinline__ bool lists_ok(const KernelArgs &a) {
     return a.static_list && a.lists_done && uniform_u32(*a.lists_done) == a.lists_tag;
 }
 
+// The kernel's argument segment through a pointer the compiler cannot see through: what is read from it is read then and
+// there (scalar loads from the constant address space), not carried in registers from wherever it was first needed.
+__device__ __forceinline__ const char *reread_kernargs(const char *kargs) {
+    unsigned long long p = uniform_u64((unsigned long long)kargs);   // (inside a function that is not inlined the pointer arrives in vector registers)
+    asm volatile("s_mov_b64 %0, %1" : "=s"(p) : "s"(p));
+    return (const char *)reinterpret_cast<const __attribute__((address_space(4))) char *>(p);
+}
+
 extern __shared__ double rm_lds[];
 
 // Every workgroup keeps its own copy of the scene in LDS; all later reads are
