@@ -22,7 +22,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = os.path.join(ROOT, "gpurun_out")
 
 for c in ("C2", "C3", "C5", "C4", "default"):
-    for f in glob.glob(os.path.join(out, "%s_trace_%s" % (tag, c), "**", "*kernel_stats.csv"), recursive=True):
+    # (an earlier collection's files may lie beside the last one's: the newest wins)
+    for f in sorted(glob.glob(os.path.join(out, "%s_trace_%s" % (tag, c), "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime):
         rows = open(f).read().splitlines()[:6]
         name = "%s_kernel_stats_%s.csv" % (tag, c if c != "default" else "default_cmd")
         open(os.path.join(ROOT, "profiles", name), "w").write("\n".join(rows) + "\n")
