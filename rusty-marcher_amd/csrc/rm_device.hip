@@ -326,7 +326,7 @@ static rm_status guarded(rm_ctx *ctx, const char *who, F &&body) {
 // 82.8 us), nothing on the 7.6 KB cornell box (153 vs 150 us) and costs 20 % on the 29 KB
 // synthetic scene (10.5 vs 8.7 ms: every workgroup re-stages the blob).
 // RM_ERR_SCENE_LIMIT is left for what the blob's 32-bit word offsets cannot address.
-static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = 4 * 1024;
+static constexpr size_t RM_LDS_SCENE_LIMIT_BYTES = RM_LDS_SCENE_LIMIT_WORDS * sizeof(double);   // (4 KB)
 static constexpr uint64_t RM_SCENE_MAX_WORDS = 0xFFFFFFF0ull;
 // A hierarchy is built over a kind once it has this many primitives (below, the flat walk
 // is as fast: the demo scene has 4 spheres).

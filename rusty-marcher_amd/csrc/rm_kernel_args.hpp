@@ -208,6 +208,8 @@ struct StackEntry {
 #define RM_WAVE_PAIR_WORDS 704u
 #define RM_WAVE_T0_WORDS 736u      /* the wave's start time (patch order) */
 #define RM_WAVE_LDS_WORDS 738u
+// Scenes up to this long are copied into every workgroup's LDS block (the STAGED kernels): 4 KB.
+#define RM_LDS_SCENE_LIMIT_WORDS 512u
 
 }  // namespace rmdev
 

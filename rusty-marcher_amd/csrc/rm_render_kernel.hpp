@@ -68,6 +68,31 @@ __device__ __forceinline__ void stage_scene(const double *__restrict__ scene_blo
     __syncthreads();
 }
 
+// The same copy in two halves: asked for when the wave starts, put into LDS once the wave knows it renders a tile at all -- the
+// loads travel while the wave finds its place in the order and its tile's classification word (measured: a wave of the demo
+// frame knew its tile after 1.07 us, its word 0.76 us later, and only then spent 0.72 us on the copy).  Scenes of the staged
+// kernels are at most RM_LDS_SCENE_LIMIT_WORDS long (rm_device.hip): four 16-byte pieces a lane.
+struct SceneAsked { double2 v[RM_LDS_SCENE_LIMIT_WORDS / 128u]; };
+__device__ __forceinline__ SceneAsked stage_scene_ask(const double *__restrict__ scene_blob, const rm_dev_header &H) {
+    const double2 *src = reinterpret_cast<const double2 *>(scene_blob);
+    const uint32_t n2 = H.total_words / 2, lane = threadIdx.x & 63u;
+    SceneAsked p;
+#pragma unroll
+    for (uint32_t k = 0; k < RM_LDS_SCENE_LIMIT_WORDS / 128u; k++) {
+        p.v[k] = double2{0., 0.};
+        if (lane + 64u * k < n2) p.v[k] = src[lane + 64u * k];
+    }
+    return p;
+}
+__device__ __forceinline__ void stage_scene_put(const SceneAsked &p, const rm_dev_header &H) {
+    double2 *dst = reinterpret_cast<double2 *>(rm_lds);
+    const uint32_t n2 = H.total_words / 2, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t k = 0; k < RM_LDS_SCENE_LIMIT_WORDS / 128u; k++)
+        if (lane + 64u * k < n2) dst[lane + 64u * k] = p.v[k];
+    __syncthreads();
+}
+
 // tile id -> pixel origin.  Patch-major: patch = id / 16 walks the band row by row
 // (renderer.rs:69-70), sub = id % 16 walks the 4x4 tiles of the patch.
 // dispatch id -> tile.  Workgroups are dispatched in id order; the affine map (a bijection:
