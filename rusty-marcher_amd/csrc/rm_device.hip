@@ -1204,7 +1204,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 RM_HIP(ctx, hipLaunchKernel(rm_classify_kernel(n_planar > 0u), dim3((a.n_tiles / 16u + 3u) / 4u), dim3(64), cargs, 0, stream));
             }
             a.tile_mask = tl->mask();
-            a.mask_exact = n_prims_all <= 64u ? 1u : 0u;
+            a.mask_exact = n_prims_all <= (in_launch ? 56u : 64u) ? 1u : 0u;      // (a tagged word names 56 primitives, rm_classify.inc)
         }
     }
     // Dispatch order from the launch's own classification, and the sky tail (KernelArgs::ord_*; rm_classify.inc place_patch /

@@ -462,6 +462,37 @@ def test_fuzz_random_scenes(pkg, O, ctx, seed):
     random frame shapes and depth caps; enough spheres in half of the cases to switch the
     hierarchy walk on.  The product and the oracle are built from the same recipe through
     their own APIs."""
+    _fuzz_case(pkg, O, ctx, seed)
+
+
+@pytest.fixture(scope="module")
+def ctx_order_forced(pkg):
+    """A context whose every launch classifies its tiles at its head and dispatches ALL of them by the order it lays out
+    (no first round): the fuzz's frames are a few hundred tiles, which by their own rules get neither."""
+    forced = {"RM_TILE_CLASSIFY": "1", "RM_PATCH_ORDER": "1", "RM_FIRST_ROUND": "0"}
+    before = {k: os.environ.get(k) for k in forced}
+    os.environ.update(forced)
+    try:
+        c = pkg.backend.Context(0)
+    finally:
+        for k, v in before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RM_FUZZ_SEEDS", "12"))))
+def test_fuzz_random_scenes_with_the_order_forced(pkg, O, ctx_order_forced, seed):
+    """The same scenes with the classification and the dispatch order forced on for every launch -- one context through all
+    of them: another scene, another frame shape, another kernel every time.  (r4: seed 2 -- 64 primitives with a hierarchy --
+    showed the words of a launch that classifies at its head, 56 bits under the tag, taken as exact for 57-64 primitives.)"""
+    _fuzz_case(pkg, O, ctx_order_forced, seed)
+
+
+def _fuzz_case(pkg, O, ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     s, so = pkg.Scene.new(), O.OracleScene()
 
