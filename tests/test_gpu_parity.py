@@ -493,6 +493,13 @@ def test_fuzz_random_scenes_with_the_order_forced(pkg, O, ctx_order_forced, seed
 
 
 def _fuzz_case(pkg, O, ctx, seed):
+    s, so, cam, w, h, depth = _fuzz_scene(pkg, O, seed)
+    gpu, _ = gpu_render(pkg, ctx, s, w, h, depth)
+    compare(gpu, O.render(so, w, h, max_depth=depth))
+
+
+def _fuzz_scene(pkg, O, seed):
+    """-> the product's scene, the oracle's, the camera, frame width and height, depth cap of fuzz case `seed`."""
     rng = np.random.default_rng(1000 + seed)
     s, so = pkg.Scene.new(), O.OracleScene()
 
@@ -542,8 +549,61 @@ def _fuzz_case(pkg, O, ctx, seed):
     so.set_camera(cam)
     w, h = int(rng.integers(1, 9)) * 32, int(rng.integers(1, 7)) * 32 + int(rng.integers(0, 2)) * 7
     depth = int(rng.integers(1, 7))
-    gpu, _ = gpu_render(pkg, ctx, s, w, h, depth)
-    compare(gpu, O.render(so, w, h, max_depth=depth))
+    return s, so, cam, w, h, depth
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RM_FUZZ_SEQ_SEEDS", "8"))))
+def test_fuzz_sequences_with_the_order_forced(pkg, O, seed):
+    """Random scenes as a host's render loop sees them: seven frames of one scene on one stream -- the view standing for five
+    (from the fourth on a launch dispatches by its predecessor's order and takes its predecessor's words), one press of the
+    camera, back again -- in a frame four times the fuzz's width and height (up to 192 patches), through contexts with the
+    classification and the order forced on and the first round cut to 0 / 64 / 256 waves, keys by place / time / content in turn.
+    Every frame must equal, bit for bit and in a buffer pre-filled with a sentinel, the frame of a context with neither; the
+    first of them is held against the oracle."""
+    import torch
+    s, so, cam, w, h, depth = _fuzz_scene(pkg, O, seed)
+    w, h, depth = 4 * w, 4 * (h - h % 32) + h % 32, min(depth, 3)
+    forced = {"RM_TILE_CLASSIFY": "1", "RM_PATCH_ORDER": "1", "RM_FIRST_ROUND": ("0", "64", "256")[seed % 3], "RM_ORDER_KEYS": ("0", "1", "2", "")[seed % 4]}
+    if not forced["RM_ORDER_KEYS"]:
+        del forced["RM_ORDER_KEYS"]
+    before = {k: os.environ.get(k) for k in list(forced) + ["RM_TILE_CLASSIFY", "RM_PATCH_ORDER"]}
+    try:
+        os.environ.update({"RM_TILE_CLASSIFY": "0", "RM_PATCH_ORDER": "0"})
+        plain = pkg.backend.Context(0)
+        os.environ.update(forced)
+        ordered = pkg.backend.Context(0)
+    finally:
+        for k, v in before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        handle = s.flatten()
+        plain.upload(handle)
+        ordered.upload(handle)
+        p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth)
+        p.flags = _FLAGS["value"]
+        cams = [cam] * 5 + [(cam[0] + 5., cam[1], cam[2]), cam]
+        for k, c in enumerate(cams):
+            outs = []
+            for ctx in (plain, ordered):
+                ctx.set_camera(pkg.Vec3f(*c))
+                dev = torch.full((h, w, 3), -7., dtype=torch.float64, device="cuda:0")
+                dev8 = torch.full((h, w, 3), 77, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                ctx.render_device_u8(p, dev.data_ptr(), dev8.data_ptr())
+                torch.cuda.synchronize()
+                outs.append((dev.cpu().numpy(), dev8.cpu().numpy()))
+            assert np.array_equal(outs[0][0], outs[1][0]), "frame %d of seed %d (%dx%d, %s): f64 frames differ in %d values" % (
+                k, seed, w, h, forced, int((outs[0][0] != outs[1][0]).sum()))
+            assert np.array_equal(outs[0][1], outs[1][1]), "frame %d of seed %d: display frames differ" % (k, seed)
+            if k == 0:
+                rows = h - h % 32
+                compare(outs[1][0][:rows], O.render(so, w, h, max_depth=depth)[:rows])
+    finally:
+        plain.close()
+        ordered.close()
 
 
 def _icosphere_obj(path, subdivisions):
