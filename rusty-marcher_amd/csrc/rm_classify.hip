@@ -30,7 +30,8 @@ template <bool EDGES>
 __global__ __launch_bounds__(64) void rm_classify_tiles_kernel(const double *__restrict__ scene_blob, KernelArgs a, ClassifyArgs o) {
     const uint32_t patch = blockIdx.x * 4u + ((threadIdx.x & 63u) >> 4);
     unsigned long long sig, own;
-    (void)classify_patches<EDGES>(scene_blob, a, patch, patch < (a.n_tiles >> 4), o.tile_mask, o.n_prims, 0u, sig, own);
+    const bool valid = patch < (a.n_tiles >> 4);
+    (void)classify_patches<EDGES>(cls_view_of_blob(scene_blob, a.H), a, patch, valid, classify_ask(a, patch, valid), o.tile_mask, o.n_prims, 0u, sig, own);
 }
 
 const void *rmdev::rm_classify_kernel(bool edges) {

@@ -239,6 +239,7 @@ struct rm_ctx {
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    bool classify_lds = true;            // RM_CLASSIFY_LDS=0: the classifying workgroups of scenes without an LDS copy read their tests' data from memory (A/B knob)
     uint32_t classify_in_launch_prims = 56;   // RM_CLASSIFY_IN_LAUNCH_PRIMS: scenes of up to this many primitives are classified at the head of the render launch
     uint32_t classify_min_tiles = 0;     // RM_CLASSIFY_MIN_TILES: launches of this many tiles and more are classified (and ordered); 0: RM_CLASSIFY_MIN_TILES, the built-in
     bool mask_reuse = true;              // RM_MASK_REUSE=0: a launch waits for its own classification even where its predecessor's is as good (A/B knob)
@@ -423,6 +424,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_CLASSIFY_LDS")) ctx->classify_lds = env[0] != '0';
     if (const char *env = std::getenv("RM_CLASSIFY_IN_LAUNCH_PRIMS")) ctx->classify_in_launch_prims = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_CLASSIFY_MIN_TILES")) ctx->classify_min_tiles = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_ORD_TAG_WRAP")) ctx->ord_tag_wrap = (uint32_t)std::max(1, std::atoi(env));
@@ -1131,7 +1133,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     a.first_round = (uint32_t)ctx->prop.multiProcessorCount * 4u * (k.edges ? RM_EDGES_WAVES : RM_MIN_WAVES);
     if (ctx->first_round >= 0) a.first_round = (uint32_t)ctx->first_round;     // (RM_FIRST_ROUND: A/B knob, and how the tests reach the order in frames of a few thousand tiles)
     const rm_launch_mode m = k.mode;
-    const size_t lds = k.lds_bytes;
+    size_t lds = k.lds_bytes;
     const dim3 block(m.waves * 64);
     const void *fn = k.fn;
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
@@ -1194,6 +1196,15 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 a.cls_blocks = (a.n_tiles / 16u + 3u) / 4u;
                 a.cls_prims = n_prims_all;
                 grid.x += a.cls_blocks;
+                // Scenes too long for an LDS copy (the Cornell box: 36 triangles, 15 KB): the classifying workgroups pack what their
+                // tests read -- bounds, lifted vertices, plane records: 4 n + 22 n_planar words -- into their LDS block, where there is
+                // room for it at the kernel's occupancy (every workgroup of the launch is given the block: 16 to a CU, 12 in the
+                // edge-test kernels, of 160 KB).  RM_CLASSIFY_LDS=0: from memory.
+                const uint32_t cls_words = 4u * n_prims_all + 22u * n_planar, rec_words = 16u * 6u;
+                if (!k.staged && ctx->classify_lds && cls_words + rec_words <= (k.edges ? 1664u : 1248u)) {
+                    a.cls_lds_words = cls_words;
+                    lds = std::max(lds, (size_t)(cls_words + rec_words) * sizeof(double));
+                }
             } else {
                 tl->tagged = false;
                 ClassifyArgs o{};
