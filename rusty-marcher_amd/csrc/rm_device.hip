@@ -1134,6 +1134,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     if (ctx->first_round >= 0) a.first_round = (uint32_t)ctx->first_round;     // (RM_FIRST_ROUND: A/B knob, and how the tests reach the order in frames of a few thousand tiles)
     const rm_launch_mode m = k.mode;
     size_t lds = k.lds_bytes;
+    uint32_t cls_words_wanted = 0u;
     const dim3 block(m.waves * 64);
     const void *fn = k.fn;
     const uint32_t per_wg = (uint32_t)(m.waves * m.per_wave);
@@ -1200,11 +1201,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 // tests read -- bounds, lifted vertices, plane records: 4 n + 22 n_planar words -- into their LDS block, where there is
                 // room for it at the kernel's occupancy (every workgroup of the launch is given the block: 16 to a CU, 12 in the
                 // edge-test kernels, of 160 KB).  RM_CLASSIFY_LDS=0: from memory.
-                const uint32_t cls_words = 4u * n_prims_all + 22u * n_planar, rec_words = 16u * 6u;
-                if (!k.staged && ctx->classify_lds && cls_words + rec_words <= (k.edges ? 1664u : 1248u)) {
-                    a.cls_lds_words = cls_words;
-                    lds = std::max(lds, (size_t)(cls_words + rec_words) * sizeof(double));
-                }
+                // (decided where the launch's geometry is final, below: the workgroups' records lie behind the packed data)
+                cls_words_wanted = (!k.staged && ctx->classify_lds) ? 4u * n_prims_all + 22u * n_planar : 0u;
             } else {
                 tl->tagged = false;
                 ClassifyArgs o{};
@@ -1230,7 +1228,9 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         const uint32_t n_patches = a.n_tiles / 16u;
         a.n_static = std::min(a.first_round & ~15u, a.n_tiles);
         const uint32_t n_dyn = n_patches - a.n_static / 16u;
-        const bool ordered = k.order && per_wg == 1u && a.cls_blocks != 0u && n_dyn > 0u && n_patches < (1u << RM_ORD_PATCH_BITS);
+        // (at most sixteen turns a classifying workgroup: its records -- 48 bytes a turn -- lie in its LDS block)
+        const bool ordered = k.order && per_wg == 1u && a.cls_blocks != 0u && n_dyn > 0u && n_patches < (1u << RM_ORD_PATCH_BITS) &&
+                             n_patches <= 16u * 4u * RM_ORD_MAX_CLS;
         if (ordered) {
             rm_tile_lists *tl = nullptr;
             rm_status ost = tile_lists_for(ctx, stream, a.n_tiles, &tl);
@@ -1370,6 +1370,15 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // 69.2 -> 68.5 -- a tile with something to hit never waits for a slot behind a wave that only stores, and the
             // tail's stores, 24-43 MB, overlap the drain); an 8K launch ends with 380 MB of them if they wait: 960 -> 1,020 us.
             if (a.tail_q > 1u && (ctx->sky_tail_place == 2 || (ctx->sky_tail_place == 0 && timed))) a.tail_q = 1u;
+        }
+    }
+    if (cls_words_wanted) {
+        // a record of three words per group of four patches and turn (OrdRec), behind the packed data; the block every workgroup
+        // of the launch is given must still let the kernel's waves all be resident: 16 workgroups to a CU, 12 in the edge-test kernels
+        const uint32_t rec_words = (std::max(a.cls_iters, 1u) * 4u * 3u + 1u) / 2u;
+        if (cls_words_wanted + rec_words <= (k.edges ? 1664u : 1248u)) {
+            a.cls_lds_words = cls_words_wanted;
+            lds = std::max(lds, (size_t)(cls_words_wanted + rec_words) * sizeof(double));
         }
     }
 #if defined(RM_EXP_STAMPS) || defined(RM_EXP_PHASES)
