@@ -239,6 +239,7 @@ struct rm_ctx {
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
+    bool cull_lds = false;               // RM_CULL_LDS=1: the render waves of scenes without an LDS copy pack the bundle cull's arrays into their LDS block (A/B knob: measured slower)
     bool classify_lds = true;            // RM_CLASSIFY_LDS=0: the classifying workgroups of scenes without an LDS copy read their tests' data from memory (A/B knob)
     uint32_t classify_in_launch_prims = 56;   // RM_CLASSIFY_IN_LAUNCH_PRIMS: scenes of up to this many primitives are classified at the head of the render launch
     uint32_t classify_min_tiles = 0;     // RM_CLASSIFY_MIN_TILES: launches of this many tiles and more are classified (and ordered); 0: RM_CLASSIFY_MIN_TILES, the built-in
@@ -424,6 +425,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_CULL_LDS")) ctx->cull_lds = env[0] == '1';
     if (const char *env = std::getenv("RM_CLASSIFY_LDS")) ctx->classify_lds = env[0] != '0';
     if (const char *env = std::getenv("RM_CLASSIFY_IN_LAUNCH_PRIMS")) ctx->classify_in_launch_prims = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_CLASSIFY_MIN_TILES")) ctx->classify_min_tiles = (uint32_t)std::max(0, std::atoi(env));
@@ -1370,6 +1372,18 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // 69.2 -> 68.5 -- a tile with something to hit never waits for a slot behind a wave that only stores, and the
             // tail's stores, 24-43 MB, overlap the drain); an 8K launch ends with 380 MB of them if they wait: 960 -> 1,020 us.
             if (a.tail_q > 1u && (ctx->sky_tail_place == 2 || (ctx->sky_tail_place == 0 && timed))) a.tail_q = 1u;
+        }
+    }
+    // RM_CULL_LDS=1: the bundle cull's arrays in every render wave's LDS block (scenes too long for a copy: the Cornell box), where
+    // the block still lets all the kernel's waves be resident.  Measured (r4, as in r2): SLOWER -- Cornell 33.7-33.8 against
+    // 32.9-33.1 us standing, 41.4-41.9 against 38.8-40.2 with the camera on the move: a wave packs 5.8 KB to spare three
+    // round trips that its SIMD's other waves cover anyway.  Off.
+    if (!k.staged && k.cull && ctx->cull_lds) {
+        const uint32_t n_planar_ = ctx->H.n_polygons + ctx->H.n_triangles;
+        const uint32_t cull_words = 4u * (ctx->H.n_spheres + n_planar_) + 16u * n_planar_;
+        if (cull_words + (uint32_t)m.waves * RM_WAVE_LDS_WORDS <= (k.edges ? 1664u : 1248u)) {
+            a.cull_lds_words = cull_words;
+            lds = std::max(lds, (size_t)(cull_words + (uint32_t)m.waves * RM_WAVE_LDS_WORDS) * sizeof(double));
         }
     }
     if (cls_words_wanted) {

@@ -117,6 +117,7 @@ struct KernelArgs {
     uint32_t cls_blocks;
     uint32_t cls_prims;
     uint32_t cls_lds_words;                  // != 0: the classifying workgroups pack what their tests read into their LDS block first (rm_classify.inc cls_stage), this many words
+    uint32_t cull_lds_words;                 // != 0: every render wave packs the bundle cull's arrays (bounds, lifted vertices: 4 n + 16 n_planar words) into its LDS block, in front of its own words
     // Dispatch order from THIS launch's classification (rm_classify.inc `order_patches`, rm_render_kernel.inc `order_entry`).
     // The reference renders only after the camera has moved (main.rs:74-78), so an order kept from earlier frames BY PLACE is
     // stale exactly when it is needed.  Instead the classifying workgroups at the launch's head, which know what each patch's
