@@ -182,6 +182,7 @@ struct rm_tile_lists {
     uint32_t tag = 0, tagged_tiles = 0;
     uint64_t tagged_scene = 0;
     bool tagged = false;
+    uint32_t frozen_run = 0;          // launches in a row that took everything from their predecessor (order_freeze)
     unsigned long long *mask() const { return static_cast<unsigned long long *>(block); }
 };
 
@@ -244,6 +245,7 @@ struct rm_ctx {
     uint32_t classify_in_launch_prims = 56;   // RM_CLASSIFY_IN_LAUNCH_PRIMS: scenes of up to this many primitives are classified at the head of the render launch
     uint32_t classify_min_tiles = 0;     // RM_CLASSIFY_MIN_TILES: launches of this many tiles and more are classified (and ordered); 0: RM_CLASSIFY_MIN_TILES, the built-in
     bool mask_reuse = true;              // RM_MASK_REUSE=0: a launch waits for its own classification even where its predecessor's is as good (A/B knob)
+    int order_freeze = 7;                // RM_ORDER_FREEZE=n: of n + 1 launches of a standing view only one classifies and lays out an order (0: every launch)
     bool order_late_places = true;       // RM_ORDER_LATE_PLACES=0: the classifying workgroups always write the order's places themselves (A/B knob)
     bool order_reuse = true;             // RM_ORDER_REUSE=0: every launch dispatches by its own order, standing view or not (A/B knob)
     bool first_round_from_order = true;  // RM_FIRST_ROUND_FROM_ORDER=0: the first round is the bottom rows by place (A/B knob)
@@ -423,6 +425,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FIRST_ROUND")) ctx->first_round = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_FIRST_ROUND_FROM_ORDER")) ctx->first_round_from_order = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_ORDER_FREEZE")) ctx->order_freeze = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
     if (const char *env = std::getenv("RM_CULL_LDS")) ctx->cull_lds = env[0] == '1';
@@ -1162,6 +1165,9 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         grid.x = a.n_tiles + fb->cap;                         // ids [0, cap): the list; the rest: the tiles in order
     }
     if (ctx->debug_empty) a.n_tiles = 0;   // RM_DEBUG_EMPTY=1: same grid, every wave exits after staging
+    rm_tile_lists tl_before{};           // the stream's lists as this launch found them (order_freeze)
+    rm_tile_lists *tl_snapped = nullptr;
+    bool frozen_launch = false;
     uint32_t mask_tag_before_ = 0u;      // the tag the previous launch on this stream gave its tiles' words (0: none that this launch could take)
     // Tile classification in front of the render launch (rm_classify.hip): tiles whose primary rays can hit
     // nothing are filled there and never get a wave; the others are listed, with the primitives their primary
@@ -1180,6 +1186,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             rm_tile_lists *tl = nullptr;
             rm_status cst = tile_lists_for(ctx, stream, a.n_tiles, &tl);
             if (cst != RM_OK) return cst;
+            tl_before = *tl;
+            tl_snapped = tl;
             // Scenes of up to 56 primitives are classified at the head of the render launch itself (its first
             // workgroups; the words carry the launch's tag): no launch of its own, no gap, and the classification
             // runs while the first round of tiles renders.  Measured at 1080p, demo scene: 82.6 us with the launch
@@ -1372,6 +1380,37 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // 69.2 -> 68.5 -- a tile with something to hit never waits for a slot behind a wave that only stores, and the
             // tail's stores, 24-43 MB, overlap the drain); an 8K launch ends with 380 MB of them if they wait: 960 -> 1,020 us.
             if (a.tail_q > 1u && (ctx->sky_tail_place == 2 || (ctx->sky_tail_place == 0 && timed))) a.tail_q = 1u;
+            // A standing view, further: a launch that dispatches by its predecessor's order and takes its predecessor's
+            // classification words computes, at its head, the very words and (but for a frame's noise in the tile times) the very
+            // order its predecessor did.  Of order_freeze + 1 such launches only one does: the others are that launch less its
+            // classifying workgroups and the workgroups that write the places -- same order read, same first round, same words
+            // (all of them there: the predecessor is over), same tail -- and leave the stream's lists as they found them, so the
+            // next launch that does classify is set up exactly as if they had not been.  Their tile times go into the same
+            // counters (a maximum, a sum and a count: of two frames then).  What it spares: ~500 waves that hold a slot for 5-13 us
+            // at the launch's start and ~500 short workgroups at its end.
+            if (ctx->order_freeze > 0 && reuse && f >= 4u && tl_snapped == tl && tl_before.frozen_run < (uint32_t)ctx->order_freeze &&
+                a.mask_tag > 1u && a.mask_tag_prev != 0u && a.ord_rec != nullptr && ctx->test_stall_order == 0 && ctx->sky_tail_force < 0 &&
+                !std::getenv("RM_DEBUG_TAIL")) {
+                frozen_launch = true;
+                a.cls_blocks = 0u; a.cls_iters = 0u; a.cls_prims = 0u;
+                a.ord_rec = nullptr; a.ord_cnt_next = nullptr;
+                a.cost_zero = nullptr; a.ctab_zero = nullptr;
+                a.static_next = nullptr; a.dyn_index_next = nullptr; a.dyn_inv_next = nullptr; a.lists_done_next = nullptr;
+                a.mask_tag = tl_before.tag;                                     // (the words as the predecessor left them)
+                a.mask_tag_prev = tl_before.tag;
+                cls_words_wanted = 0u;
+                grid.x = a.n_static + 16u * (n_dyn - tail) + tail + 16u * cap;
+                // (the lists as they were; only the count of launches like this one moves)
+                const uint32_t run = tl_before.frozen_run + 1u;
+                tl->order_frames = tl_before.order_frames; tl->seq = tl_before.seq; tl->key_seq0 = tl_before.key_seq0;
+                tl->view_seq0 = tl_before.view_seq0; tl->ord_tag = tl_before.ord_tag; tl->last_tag = tl_before.last_tag;
+                tl->list_tag[0] = tl_before.list_tag[0]; tl->list_tag[1] = tl_before.list_tag[1];
+                tl->static_read = tl_before.static_read; tl->static_written = tl_before.static_written;
+                tl->tag = tl_before.tag; tl->tagged = tl_before.tagged; tl->tagged_tiles = tl_before.tagged_tiles; tl->tagged_scene = tl_before.tagged_scene;
+                tl->frozen_run = run;
+            } else {
+                tl->frozen_run = 0u;
+            }
         }
     }
     // RM_CULL_LDS=1: the bundle cull's arrays in every render wave's LDS block (scenes too long for a copy: the Cornell box), where

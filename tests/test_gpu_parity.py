@@ -554,9 +554,9 @@ def _fuzz_scene(pkg, O, seed):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RM_FUZZ_SEQ_SEEDS", "8"))))
 def test_fuzz_sequences_with_the_order_forced(pkg, O, seed):
-    """Random scenes as a host's render loop sees them: seven frames of one scene on one stream -- the view standing for five
-    (from the fourth on a launch dispatches by its predecessor's order and takes its predecessor's words), one press of the
-    camera, back again -- in a frame four times the fuzz's width and height (up to 192 patches), through contexts with the
+    """Random scenes as a host's render loop sees them: seventeen frames of one scene on one stream -- the view standing for ten
+    (from the fourth on a launch dispatches by its predecessor's order and takes its predecessor's words, from the fifth on
+    three launches in four do not classify at all), one press of the camera, back again for six -- in a frame four times the fuzz's width and height (up to 192 patches), through contexts with the
     classification and the order forced on and the first round cut to 0 / 64 / 256 waves, keys by place / time / content in turn.
     Every frame must equal, bit for bit and in a buffer pre-filled with a sentinel, the frame of a context with neither; the
     first of them is held against the oracle."""
@@ -587,7 +587,8 @@ def test_fuzz_sequences_with_the_order_forced(pkg, O, seed):
         band = (seed % 2, n_rows, 2 + seed % 2) if seed % 5 == 4 and n_rows >= 4 else None
         p = pkg.backend.make_params(workloads.FOV, float(h), float(w), depth, band)
         p.flags = _FLAGS["value"]
-        cams = [cam] * 5 + [(cam[0] + 5., cam[1], cam[2]), cam]
+        # (ten frames of one view: from the fifth on, three launches in four take order and classification from their predecessor)
+        cams = [cam] * 10 + [(cam[0] + 5., cam[1], cam[2])] + [cam] * 6
         for k, c in enumerate(cams):
             outs = []
             for ctx in (plain, ordered):
