@@ -563,7 +563,8 @@ def test_fuzz_sequences_with_the_order_forced(pkg, O, seed):
     import torch
     s, so, cam, w, h, depth = _fuzz_scene(pkg, O, seed)
     w, h, depth = 4 * w, 4 * (h - h % 32) + h % 32, min(depth, 3)
-    forced = {"RM_TILE_CLASSIFY": "1", "RM_PATCH_ORDER": "1", "RM_FIRST_ROUND": ("0", "64", "256")[seed % 3], "RM_ORDER_KEYS": ("0", "1", "2", "")[seed % 4]}
+    forced = {"RM_TILE_CLASSIFY": "1", "RM_PATCH_ORDER": "1", "RM_FIRST_ROUND": ("0", "64", "256")[seed % 3], "RM_ORDER_KEYS": ("0", "1", "2", "")[seed % 4],
+              "RM_ORDER_FREEZE": ("1", "2", "3", "7", "0")[seed % 5]}
     if not forced["RM_ORDER_KEYS"]:
         del forced["RM_ORDER_KEYS"]
     before = {k: os.environ.get(k) for k in list(forced) + ["RM_TILE_CLASSIFY", "RM_PATCH_ORDER"]}
