@@ -62,8 +62,9 @@ ORDER_NOTE = ("dispatch order from the launch's own classification: its classify
               "(RM_PATCH_ORDER=0 switches it off); sky tail: the places of the order nothing can be hit in get one wave instead of sixteen, "
               "their number taken from a hint the earlier launches left in page-locked memory -- exact for a standing view, a guess for a "
               "moved one, whose wrong places are rendered by sixteen waves each at the grid's end (RM_SKY_TAIL=0 switches it off); only the "
-              "order and the geometry of a launch depend on any of it: every frame classifies every patch and every pixel with something "
-              "to hit is traced in full, exactly once")
+              "order and the geometry of a launch depend on any of it: every frame whose view, scene or size differs from its predecessor's "
+              "classifies every patch (of eight launches of a standing view one does, the others take their predecessor's words and order: "
+              "RM_ORDER_FREEZE=0 makes every launch classify) and every pixel with something to hit is traced in full, exactly once")
 MOTION_NOTE = ("the reference renders only after a camera move or a scene change (main.rs:74-78, :119-170): rm_camera_update before "
                "EVERY launch, the camera one button press (+-5 on one axis) from where it was (workloads.camera_walk), the scene "
                "resident; same stream, same outputs, same HIP-event bracket around the K steps as the metric")
