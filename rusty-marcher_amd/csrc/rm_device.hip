@@ -245,6 +245,8 @@ struct rm_ctx {
     uint32_t classify_in_launch_prims = 56;   // RM_CLASSIFY_IN_LAUNCH_PRIMS: scenes of up to this many primitives are classified at the head of the render launch
     uint32_t classify_min_tiles = 0;     // RM_CLASSIFY_MIN_TILES: launches of this many tiles and more are classified (and ordered); 0: RM_CLASSIFY_MIN_TILES, the built-in
     bool mask_reuse = true;              // RM_MASK_REUSE=0: a launch waits for its own classification even where its predecessor's is as good (A/B knob)
+    uint32_t static_rounds = 2;          // RM_STATIC_ROUNDS=n: n rounds of waves take their patches from the previous ranking without waiting for the order (A/B knob)
+    uint32_t cls_max_blocks = RM_ORD_MAX_CLS;   // RM_CLS_MAX_BLOCKS=n: at most n classifying workgroups (each then takes more groups of four patches; A/B knob)
     int order_freeze = 7;                // RM_ORDER_FREEZE=n: of n + 1 launches of a standing view only one classifies and lays out an order (0: every launch)
     bool order_late_places = true;       // RM_ORDER_LATE_PLACES=0: the classifying workgroups always write the order's places themselves (A/B knob)
     bool order_reuse = true;             // RM_ORDER_REUSE=0: every launch dispatches by its own order, standing view or not (A/B knob)
@@ -425,6 +427,8 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_FIRST_ROUND")) ctx->first_round = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_FIRST_ROUND_FROM_ORDER")) ctx->first_round_from_order = env[0] != '0';
     if (const char *env = std::getenv("RM_ORDER_REUSE")) ctx->order_reuse = env[0] != '0';
+    if (const char *env = std::getenv("RM_STATIC_ROUNDS")) ctx->static_rounds = (uint32_t)std::max(1, std::atoi(env));
+    if (const char *env = std::getenv("RM_CLS_MAX_BLOCKS")) ctx->cls_max_blocks = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_ORDER_FREEZE")) ctx->order_freeze = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_ORDER_LATE_PLACES")) ctx->order_late_places = env[0] != '0';
     if (const char *env = std::getenv("RM_MASK_REUSE")) ctx->mask_reuse = env[0] != '0';
@@ -1236,11 +1240,17 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
     // the same code, exactly once.
     {
         const uint32_t n_patches = a.n_tiles / 16u;
-        a.n_static = std::min(a.first_round & ~15u, a.n_tiles);
+        // (the waves that take their patches from the previous ranking and wait for no order: static_rounds times what is resident at
+        // once -- those behind the first of them start when its tiles are done, their classification words are there by then)
+        // (two rounds where the launch is at least four deep: a rank's share of a frame keeps one and its order.  Measured with a
+        // press before every frame, 1 / 2 / 3 rounds: Cornell 38.9-40.0 / 37.2 / 38.8-38.9 us, standing 30.0-30.4 / 29.8-29.9 / 31.4;
+        // demo within its noise)
+        const uint64_t rounds = (uint64_t)a.first_round * ctx->static_rounds * 2u <= a.n_tiles ? ctx->static_rounds : 1u;
+        a.n_static = (uint32_t)std::min<uint64_t>(((uint64_t)a.first_round * rounds) & ~15ull, a.n_tiles);
         const uint32_t n_dyn = n_patches - a.n_static / 16u;
         // (at most sixteen turns a classifying workgroup: its records -- 48 bytes a turn -- lie in its LDS block)
         const bool ordered = k.order && per_wg == 1u && a.cls_blocks != 0u && n_dyn > 0u && n_patches < (1u << RM_ORD_PATCH_BITS) &&
-                             n_patches <= 16u * 4u * RM_ORD_MAX_CLS;
+                             n_patches <= 16u * 4u * std::min<uint32_t>(RM_ORD_MAX_CLS, std::max(1u, ctx->cls_max_blocks));
         if (ordered) {
             rm_tile_lists *tl = nullptr;
             rm_status ost = tile_lists_for(ctx, stream, a.n_tiles, &tl);
@@ -1288,7 +1298,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
             // at most 1,024 of them, each taking as many groups of four patches, one after the other, as that needs
             grid.x -= a.cls_blocks;
             const uint32_t groups4 = (n_patches + 3u) / 4u;
-            a.cls_iters = (groups4 + RM_ORD_MAX_CLS - 1u) / RM_ORD_MAX_CLS;
+            const uint32_t cls_max = std::min<uint32_t>(RM_ORD_MAX_CLS, std::max(1u, ctx->cls_max_blocks));
+            a.cls_iters = (groups4 + cls_max - 1u) / cls_max;
             a.cls_blocks = (groups4 + a.cls_iters - 1u) / a.cls_iters;
             a.ord_cnt = tl->cnt(f & 1u);
             a.ord_cnt_next = tl->cnt((f + 1u) & 1u);
