@@ -1379,7 +1379,11 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 // (room to hand on: a press of the reference's buttons turns a few hundred of a 1080p frame's 1,980 patches)
                 // (a count from this very view is exact -- which patches went first does not change it -- but a place too many in the
                 // tail with nobody to hand it to costs sixteen tiles one after the other: a little room all the same)
-                if (tail) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : guess ? std::max(512u, n_patches / 16u) : 32u);
+                // (a guess's room, a press before every frame, 512 / 768 / 1,024 places: demo 50.2 / 47.9 / 47.8 us, Cornell 37.1 / - / 38.2 --
+                // the walk turns up to 700 of the demo's patches at a press; a place beyond the room costs sixteen tiles one after the
+                // other, an empty place sixteen waves that look and leave.  Sizing the room from how wrong the stream's recent guesses
+                // were was tried and is worse, 60-80 us: the shortfall is mostly small and now and then 500)
+                if (tail) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : guess ? std::max(768u, n_patches / 16u) : 32u);
             }
             a.tail_patches = tail;
             a.ov_cap = cap;
