@@ -67,7 +67,9 @@ ORDER_NOTE = ("dispatch order from the launch's own classification: its classify
               "RM_ORDER_FREEZE=0 makes every launch classify) and every pixel with something to hit is traced in full, exactly once")
 MOTION_NOTE = ("the reference renders only after a camera move or a scene change (main.rs:74-78, :119-170): rm_camera_update before "
                "EVERY launch, the camera one button press (+-5 on one axis) from where it was (workloads.camera_walk), the scene "
-               "resident; same stream, same outputs, same HIP-event bracket around the K steps as the metric")
+               "resident; same stream, same outputs, the same kind of HIP-event bracket as the metric's, around whole laps of the closed "
+               "walk (at least K steps: `steps` says how many -- K steps from wherever the warm-up stops are K views of a walk whose "
+               "views take 40 to 60 us)")
 WARMUP_SECONDS = float(os.environ.get("RM_BENCH_WARMUP_S", "0.3"))   # launches before the timed region, on top of --warmup (clocks settle; the profiling passes shorten it)
 WARMUP_PROBE = 8                # launches timed to find out how many that is
 
@@ -587,9 +589,11 @@ def rank_main(args):
                 dist.barrier()
                 torch.cuda.synchronize()                 # (the barrier is a collective on the device)
 
-        def timed(step, direct):
+        def timed(step, direct, n_steps=None):
             """--warmup steps + launches until WARMUP_SECONDS have passed (the same count on
-            every rank), then EXACTLY `steps` steps between fences; max over ranks."""
+            every rank), then EXACTLY `steps` steps between fences; max over ranks.
+            (`n_steps`: a leg beside the metric that times another number of steps.)"""
+            n = n_steps or steps
             counter[0] = 0
             for _ in range(warmup):
                 step()
@@ -614,7 +618,7 @@ def rank_main(args):
             fence(direct)
             t0 = time.perf_counter()
             ev0.record(stream)
-            for _ in range(steps):
+            for _ in range(n):
                 step()
             t_enq = time.perf_counter()
             ev1.record(stream)
@@ -622,7 +626,7 @@ def rank_main(args):
             elapsed = time.perf_counter() - t0
             if os.environ.get("RM_BENCH_TRACE"):
                 sys.stderr.write("[bench] bracket: %d steps, wall %.1f us, enqueued after %.1f us, events %.1f us\n"
-                                 % (steps, elapsed * 1e6, (t_enq - t0) * 1e6, ev0.elapsed_time(ev1) * 1e3))
+                                 % (n, elapsed * 1e6, (t_enq - t0) * 1e6, ev0.elapsed_time(ev1) * 1e3))
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             if use_dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -631,9 +635,9 @@ def rank_main(args):
             # N = 1 the events bracket exactly the K launches on their stream; with frames in
             # flight on the slots' own streams there is no per-launch bracket, the per-frame
             # time of the pipeline is reported instead
-            kernel_ms = ev0.elapsed_time(ev1) / steps if not direct else elapsed / steps * 1e3
-            return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kernel_ms,
-                    "mpx": (w * h) * steps / elapsed / 1e6}
+            kernel_ms = ev0.elapsed_time(ev1) / n if not direct else elapsed / n * 1e3
+            return {"elapsed": elapsed, "ms_per_step": elapsed / n * 1e3, "kernel_ms": kernel_ms,
+                    "mpx": (w * h) * n / elapsed / 1e6}
 
         paths = {}
         chosen = "none"
@@ -695,8 +699,11 @@ def rank_main(args):
         moving = None
         if motion and not use_dist:
             # (after the metric's own run: the standing view's history is on the stream, as in a host that has just stopped)
-            mv = timed(step_walk, False)
-            moving = {"value": mv["mpx"], "unit": "Mpixels/s", "steps": steps, "ms_per_step": mv["ms_per_step"],
+            # (whole laps of the walk: K steps from wherever the warm-up happened to stop are K views of a closed walk whose views
+            # take 40 to 60 us -- the driver's 20 steps read 43.7 to 55.3 us from run to run)
+            n_walk = -(-max(steps, 1) // len(walk)) * len(walk)
+            mv = timed(step_walk, False, n_walk)
+            moving = {"value": mv["mpx"], "unit": "Mpixels/s", "steps": n_walk, "ms_per_step": mv["ms_per_step"],
                       "kernel_ms": mv["kernel_ms"], "camera": "every frame one press from the last", "what": MOTION_NOTE}
             # a view held for four frames: its first frame and its fourth, each launch in an event bracket of its own
             firsts, fourths = [], []
