@@ -1464,7 +1464,8 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
         uint32_t c[RM_ORD_BUCKETS] = {}, c1[RM_ORD_BUCKETS] = {}, raw[RM_ORD_ARRIVE] = {};
         RM_HIP(ctx, hipStreamSynchronize(stream));
         RM_HIP(ctx, hipMemcpy(raw, a.ord_cnt, sizeof raw, hipMemcpyDeviceToHost));
-        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++) { c[b] = raw[b * RM_ORD_LINE]; c1[b] = raw[RM_ORD_FIRST + b * RM_ORD_LINE]; }
+        for (uint32_t b = 0; b < RM_ORD_BUCKETS; b++)
+            for (uint32_t u = 0; u < RM_ORD_SUBS; u++) { c[b] += raw[(b * RM_ORD_SUBS + u) * RM_ORD_LINE]; c1[b] += raw[RM_ORD_FIRST + (b * RM_ORD_SUBS + u) * RM_ORD_LINE]; }
         uint32_t lit = 0;
         for (uint32_t b = 0; b < RM_ORD_SKY; b++) lit += c[b];
         std::fprintf(stderr, "[rm_order] launch %u keys %u: %u classifying workgroups x %u, first round %u waves, %u + %u sky places; tail %u, room to hand on %u, handed on %u; buckets", a.launch_seq, a.key_mode,

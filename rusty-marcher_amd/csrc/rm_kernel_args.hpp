@@ -24,8 +24,12 @@
    another): [b] ordered patches in bucket b | [16 + b] first-round patches in bucket b | [32 + g] classifying workgroups of the g-th 32 that
    have arrived | groups complete | go */
 #define RM_ORD_LINE 32u
-#define RM_ORD_FIRST (RM_ORD_BUCKETS * RM_ORD_LINE)          /* [16 + b] patches of the FIRST ROUND in bucket b (for the next launch's first round) */
-#define RM_ORD_ARRIVE (2u * RM_ORD_BUCKETS * RM_ORD_LINE)
+/* every bucket counts into RM_ORD_SUBS counters, a classifying workgroup into the one of its number: the sky's counter took ~400
+   atomics of a launch's 495 workgroups, which take their turns at ~70 a microsecond; four lines a bucket, one lane a counter */
+#define RM_ORD_SUBS 4u
+#define RM_ORD_COUNTERS (RM_ORD_BUCKETS * RM_ORD_SUBS)
+#define RM_ORD_FIRST (RM_ORD_COUNTERS * RM_ORD_LINE)         /* the same again: patches of the FIRST ROUND by bucket (for the next launch's first round) */
+#define RM_ORD_ARRIVE (2u * RM_ORD_COUNTERS * RM_ORD_LINE)
 #define RM_ORD_GROUPS (RM_ORD_ARRIVE + (RM_ORD_MAX_CLS / 32u) * RM_ORD_LINE)
 #define RM_ORD_GO (RM_ORD_GROUPS + RM_ORD_LINE)
 #define RM_ORD_CNT_WORDS (RM_ORD_GO + RM_ORD_LINE)
