@@ -236,7 +236,8 @@ struct rm_ctx {
     uint32_t patch_order_max = 4096;     // RM_PATCH_ORDER_MAX: launches of up to this many patches take the kernels with the patch order
     uint32_t patch_order_max_deep = 65536;   // RM_PATCH_ORDER_MAX_DEEP: ... in scenes with a hierarchy (tile times with a long tail)
     uint32_t sky_tail_big_min = 16384;   // RM_SKY_TAIL_BIG_MIN (patches; see RM_SKY_TAIL_BIG_MIN_PATCHES)
-    bool sky_tail_big = false;            // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
+    uint32_t sky_tail_room_div = 16;     // RM_SKY_TAIL_ROOM_DIV: a guessed tail's room in launches of many patches: patches / this (A/B knob)
+    bool sky_tail_big = true;             // RM_SKY_TAIL_BIG=0: launches of more than patch_order_max patches keep the kernels without the patch order
     bool sky_tail_motion = true;         // RM_SKY_TAIL_MOTION=0: no tail in a frame whose view differs from the frames the hint came from
     int sky_tail_place = 0;              // RM_SKY_TAIL_PLACE=even|end: the tail's waves dealt out among the tile waves / behind them (unset: behind them in launches of up to patch_order_max patches)
     int sky_tail_cap = -1;               // RM_SKY_TAIL_CAP=n: places a guessed tail can hand on to waves behind the grid's end (unset: max(512, patches / 16))
@@ -419,6 +420,7 @@ rm_status rm_init(int device_ordinal, rm_ctx **out) {
     if (const char *env = std::getenv("RM_PATCH_ORDER_MAX")) ctx->patch_order_max = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG")) ctx->sky_tail_big = env[0] != '0';
     if (const char *env = std::getenv("RM_PATCH_ORDER_MAX_DEEP")) ctx->patch_order_max_deep = (uint32_t)std::max(0, std::atoi(env));
+    if (const char *env = std::getenv("RM_SKY_TAIL_ROOM_DIV")) ctx->sky_tail_room_div = (uint32_t)std::max(1, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_BIG_MIN")) ctx->sky_tail_big_min = (uint32_t)std::max(0, std::atoi(env));
     if (const char *env = std::getenv("RM_SKY_TAIL_PLACE")) ctx->sky_tail_place = env[0] == 'e' && env[1] == 'v' ? 1 : env[0] == 'e' ? 2 : 0;
     if (const char *env = std::getenv("RM_SKY_TAIL_MOTION")) ctx->sky_tail_motion = env[0] != '0';
@@ -1383,7 +1385,7 @@ static rm_status launch_render(rm_ctx *ctx, const rm_params *p, const rm_band &b
                 // the walk turns up to 700 of the demo's patches at a press; a place beyond the room costs sixteen tiles one after the
                 // other, an empty place sixteen waves that look and leave.  Sizing the room from how wrong the stream's recent guesses
                 // were was tried and is worse, 60-80 us: the shortfall is mostly small and now and then 500)
-                if (tail) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : guess ? std::max(768u, n_patches / 16u) : 32u);
+                if (tail) cap = std::min(tail, ctx->sky_tail_cap >= 0 ? (uint32_t)ctx->sky_tail_cap : guess ? std::max(768u, n_patches / ctx->sky_tail_room_div) : 32u);
             }
             a.tail_patches = tail;
             a.ov_cap = cap;
