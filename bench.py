@@ -789,10 +789,20 @@ def rank_main(args):
                     if args.fast_fp:
                         cmd += ["--fast-fp"]
                     if cfg["scene"] in ("demo", "cornell"):
-                        pr = subprocess.run(cmd, capture_output=True, timeout=300)
-                        line = pr.stdout.decode().strip().splitlines()[-1] if pr.stdout.strip() else ""
+                        # (the host side of these calls -- eight scatter threads -- shares the box's cores with other tenants: one
+                        # run of twenty calls read 0.63 ms, the next 1.02; three runs, the quickest kept, all three reported)
+                        runs, pr, line = [], None, ""
+                        for _ in range(3):
+                            pr_k = subprocess.run(cmd, capture_output=True, timeout=300)
+                            line_k = pr_k.stdout.decode().strip().splitlines()[-1] if pr_k.stdout.strip() else ""
+                            ok_k = pr_k.returncode == 0 and line_k.startswith("{")
+                            ms_k = json.loads(line_k)["rows_of_rows"]["ms_per_call"] if ok_k else None
+                            if pr is None or (ok_k and (not runs or all(r is None or ms_k <= r for r in runs))):
+                                pr, line = pr_k, line_k
+                            runs.append(ms_k)
                         if pr.returncode == 0 and line.startswith("{"):
                             sj = json.loads(line)
+                            sj["rows_of_rows"]["ms_per_call_of_each_run"] = runs
                             host["rows_of_rows"] = dict(sj["rows_of_rows"], value=sj["rows_of_rows"]["mpx_per_s"], unit="Mpixels/s",
                                                         host_threads=sj["host_threads"])
                             host["display_only"] = sj["display_only"]
